@@ -1,0 +1,165 @@
+// extern "C" boundary of libm355dist.so (declarations and reference citations: include/m355_dist.h).
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+
+#include "m355_elemwise.h"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+// Fixed-order sum of the per-workgroup partials (one workgroup): deterministic total.
+__global__ __launch_bounds__(m355::kBlock) void k_final(const double* __restrict__ partials, int nparts,
+                                                          double* __restrict__ out) {
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < nparts; i += m355::kBlock) acc += partials[i];
+  acc = m355::block_reduce_sum(acc);
+  if (threadIdx.x == 0) out[0] = acc;
+}
+
+bool convert(const m355_operand& in, long long n, bool is_param, m355::DevOperand& out, const char* what) {
+  out.ptr = in.ptr;
+  out.scalar = in.scalar;
+  out.dtype = in.dtype;
+  out.div = 1;
+  out.mod = 1;
+  if (in.ptr == nullptr) return true;
+  if (in.dtype != M355_F64 && (is_param || (in.dtype != M355_F32 && in.dtype != M355_I64))) {
+    fail(M355_ERR_INVALID, "%s: dtype %d not accepted here", what, in.dtype);
+    return false;
+  }
+  if (in.div < 1 || in.mod < 1) {
+    fail(M355_ERR_INVALID, "%s: div and mod must be >= 1 (got %lld, %lld)", what, (long long)in.div,
+         (long long)in.mod);
+    return false;
+  }
+  out.div = (unsigned long long)in.div;
+  out.mod = (unsigned long long)in.mod;
+  (void)n;
+  return true;
+}
+
+int nparams_of(int dist) {
+  switch (dist) {
+    case M355_NORMAL: return 2;
+    case M355_GAMMA: return 2;
+    case M355_BETA: return 2;
+    case M355_STUDENTT: return 3;
+    case M355_POISSON: return 1;
+    case M355_BINOMIAL: return 2;
+  }
+  return -1;
+}
+
+int build_args(int dist, int fn, int out_dtype, int64_t n, const m355_operand* x, int nparams,
+               const m355_operand* params, m355::LaunchArgs& a) {
+  const int np = nparams_of(dist);
+  if (np < 0) return fail(M355_ERR_INVALID, "unknown distribution id %d", dist);
+  if (!m355::supported(dist, fn)) return fail(M355_ERR_UNSUPPORTED, "function %d of distribution %d is not on the path", fn, dist);
+  if (nparams != np) return fail(M355_ERR_INVALID, "distribution %d takes %d parameters, got %d", dist, np, nparams);
+  if (n < 0) return fail(M355_ERR_INVALID, "n must be >= 0");
+  if (x == nullptr || params == nullptr) return fail(M355_ERR_INVALID, "x and params must not be NULL");
+  if (out_dtype != M355_F64 && out_dtype != M355_F32) return fail(M355_ERR_INVALID, "out_dtype must be f64 or f32");
+  a.fn = fn;
+  a.out_dtype = out_dtype;
+  a.n = n;
+  a.nparams = np;
+  if (!convert(*x, n, false, a.x, "x")) return M355_ERR_INVALID;
+  for (int q = 0; q < 3; ++q) {
+    a.p[q] = m355::DevOperand{nullptr, 0.0, 1, 1, M355_F64};
+    if (q < np && !convert(params[q], n, true, a.p[q], "parameter")) return M355_ERR_INVALID;
+  }
+  return M355_OK;
+}
+
+int dispatch(int dist, const m355::LaunchArgs& a) {
+  switch (dist) {
+    case M355_NORMAL: return m355_launch_normal(a);
+    case M355_GAMMA: return m355_launch_gamma(a);
+    case M355_BETA: return m355_launch_beta(a);
+    case M355_STUDENTT: return m355_launch_studentt(a);
+    case M355_POISSON: return m355_launch_poisson(a);
+    case M355_BINOMIAL: return m355_launch_binomial(a);
+  }
+  return -1000;
+}
+
+int check_launch(int rc) {
+  if (rc == 0) return M355_OK;
+  if (rc == -1000) return fail(M355_ERR_UNSUPPORTED, "(dist, fn) pair has no kernel");
+  return fail(M355_ERR_LAUNCH, "HIP launch failed: %s", hipGetErrorString((hipError_t)rc));
+}
+
+}  // namespace
+
+extern "C" {
+
+int m355_version(void) { return M355_VERSION; }
+
+const char* m355_last_error(void) { return g_err; }
+
+int m355_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  return n;
+}
+
+int m355_elemwise(int dist, int fn, int out_dtype, int64_t n, const m355_operand* x, int nparams,
+                  const m355_operand* params, void* out, void* stream) {
+  m355::LaunchArgs a{};
+  const int rc = build_args(dist, fn, out_dtype, n, x, nparams, params, a);
+  if (rc != M355_OK) return rc;
+  if (n == 0) return M355_OK;
+  if (out == nullptr) return fail(M355_ERR_INVALID, "out must not be NULL");
+  a.out = out;
+  a.partials = nullptr;
+  a.nblocks_out = nullptr;
+  a.stream = static_cast<hipStream_t>(stream);
+  return check_launch(dispatch(dist, a));
+}
+
+size_t m355_sumlogp_workspace_bytes(void) { return (size_t)4 * m355::kMaxBlocks * sizeof(double); }
+
+int m355_sumlogp(int dist, int fn, int64_t n, const m355_operand* x, int nparams,
+                 const m355_operand* params, double* out_sum, void* workspace, size_t workspace_bytes,
+                 void* stream) {
+  m355::LaunchArgs a{};
+  const int rc = build_args(dist, fn, M355_F64, n, x, nparams, params, a);
+  if (rc != M355_OK) return rc;
+  if (fn != M355_LOGPDF && fn != M355_LOGCDF && fn != M355_LOGSF)
+    return fail(M355_ERR_UNSUPPORTED, "sum-logp is defined for logpdf/logcdf/logsf only");
+  if (out_sum == nullptr || workspace == nullptr) return fail(M355_ERR_INVALID, "out_sum and workspace must not be NULL");
+  if (workspace_bytes < m355_sumlogp_workspace_bytes())
+    return fail(M355_ERR_WORKSPACE, "workspace of %zu bytes is smaller than the required %zu", workspace_bytes,
+                m355_sumlogp_workspace_bytes());
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (n == 0) {
+    hipError_t e = hipMemsetAsync(out_sum, 0, sizeof(double), s);
+    return e == hipSuccess ? M355_OK : fail(M355_ERR_LAUNCH, "hipMemsetAsync: %s", hipGetErrorString(e));
+  }
+  int nblocks = 0;
+  a.out = nullptr;
+  a.partials = static_cast<double*>(workspace);
+  a.nblocks_out = &nblocks;
+  a.stream = s;
+  const int rc2 = check_launch(dispatch(dist, a));
+  if (rc2 != M355_OK) return rc2;
+  hipLaunchKernelGGL(k_final, dim3(1), dim3(m355::kBlock), 0, s, static_cast<const double*>(workspace), nblocks,
+                     out_sum);
+  return check_launch((int)hipGetLastError());
+}
+
+}  // extern "C"

@@ -1,0 +1,323 @@
+// Per-distribution scalar bodies: what one element of the reference's fused Elemwise loop
+// computes.  Dist<D>::derive() turns the raw parameters into the loop-invariant constants
+// (gammaln/log of parameters, reciprocals) and Dist<D>::eval<FN>() is the per-element body.
+// pt.switch is a select: only the selected arm's value is produced (identical result, the dead
+// arm's NaNs never leak).  file:line citations refer to /root/reference/pytensor_distributions.
+#pragma once
+#include "m355_math.h"
+#include "m355_special.h"
+#include "../../include/m355_dist.h"
+
+namespace m355 {
+
+template <int D> struct Dist;
+
+// ------------------------------------------------------------------------------- helper.py:29-54
+M355_DEV double ppf_bounds_cont(double v, double q, double lower, double upper) {
+  double r = (q == 1.0) ? upper : v;
+  r = (q == 0.0) ? lower : r;
+  return ((q < 0.0) | (q > 1.0)) ? kNaN : r;
+}
+// helper.py:4-26
+M355_DEV double cdf_bounds(double p, double x, double lower, double upper) {
+  double r = (x >= upper) ? 1.0 : p;
+  return (x < lower) ? 0.0 : r;
+}
+// helper.py:90-91
+M355_DEV double sf_bounds(double v, double q, double lower, double upper) {
+  double r = (q > upper) ? 0.0 : v;
+  return (q < lower) ? 1.0 : r;
+}
+
+// --------------------------------------------------------------------------------------- normal
+// normal.logcdf body on a standardised z (normal.py:70-76).
+M355_DEV double normal_logcdf_z(double z) {
+  if (z < -1.0) {
+    return flog(0.5 * erfcx_(-z * kInvSqrt2)) - 0.5 * z * z;
+  }
+  return flog1p(-0.5 * erfc_(z * kInvSqrt2));
+}
+
+template <> struct Dist<M355_NORMAL> {
+  static constexpr int NP = 2;
+  struct K {
+    double mu, sigma, inv_sigma, c;
+  };
+  static M355_HD K derive(const double* p) {
+    K k;
+    k.mu = p[0];
+    k.sigma = p[1];
+    k.inv_sigma = 1.0 / p[1];
+    k.c = -kLogSqrt2Pi - flog(p[1]);
+    return k;
+  }
+  template <int FN> static M355_DEV double eval(double x, const K& k) {
+    if constexpr (FN == M355_LOGPDF) {  // normal.py:79-80
+      const double z = (x - k.mu) * k.inv_sigma;
+      return __builtin_fma(-0.5 * z, z, k.c);
+    } else if constexpr (FN == M355_PDF) {  // normal.py:54-55
+      const double z = (x - k.mu) / k.sigma;
+      return 1.0 / sqrt_(2.0 * kPi * k.sigma * k.sigma) * exp_(-0.5 * z * z);
+    } else if constexpr (FN == M355_LOGCDF) {  // normal.py:70-76
+      return normal_logcdf_z((x - k.mu) / k.sigma);
+    } else if constexpr (FN == M355_LOGSF) {  // normal.py:83-84: logcdf(-x, -mu, sigma)
+      return normal_logcdf_z((-x + k.mu) / k.sigma);
+    } else if constexpr (FN == M355_SF) {  // normal.py:62-63
+      return exp_(normal_logcdf_z((-x + k.mu) / k.sigma));
+    } else if constexpr (FN == M355_CDF) {  // normal.py:46-47
+      return 0.5 * (1.0 + erf_((x - k.mu) / (k.sigma * kSqrt2)));
+    } else if constexpr (FN == M355_PPF || FN == M355_ISF) {  // normal.py:58-59, 50-51
+      const double q = (FN == M355_ISF) ? 1.0 - x : x;
+      const double v = k.mu + k.sigma * kSqrt2 * erfinv_(2.0 * q - 1.0);
+      return ppf_bounds_cont(v, q, -kInf, kInf);
+    }
+    return kNaN;
+  }
+};
+
+// ---------------------------------------------------------------------------------------- gamma
+template <> struct Dist<M355_GAMMA> {
+  static constexpr int NP = 2;
+  struct K {
+    double alpha, beta, am1, c, lga;
+  };
+  static M355_HD K derive(const double* p) {
+    K k;
+    k.alpha = p[0];
+    k.beta = p[1];
+    k.am1 = p[0] - 1.0;
+    k.lga = lgamma_(p[0]);
+    k.c = p[0] * flog(p[1]) - k.lga;
+    return k;
+  }
+  // gamma.py:77-82 with (alpha-1)*log(x) as xlogy0 (quirk Q2).
+  static M355_DEV double logpdf(double x, const K& k) {
+    const double t = xlogy0_l(k.am1, flog(x));
+    const double r = (t - x * k.beta) + k.c;
+    return (x < 0.0) ? -kInf : r;
+  }
+  // gamma.py:65-74
+  static M355_DEV double logcdf(double x, const K& k) {
+    const double xb = x * k.beta;
+    double r;
+    if (xb < k.alpha) {
+      r = flog(gammainc_p(k.alpha, xb, k.lga));
+    } else {
+      r = flog1p(-gammainc_q(k.alpha, xb, k.lga));
+    }
+    return (x < 0.0) ? -kInf : r;
+  }
+  // gamma.py:85-94
+  static M355_DEV double logsf(double x, const K& k) {
+    const double xb = x * k.beta;
+    double r;
+    if (xb < k.alpha) {
+      r = flog1p(-gammainc_p(k.alpha, xb, k.lga));
+    } else {
+      r = flog(gammainc_q(k.alpha, xb, k.lga));
+    }
+    return (x < 0.0) ? 0.0 : r;
+  }
+  // gamma.py:48-50
+  static M355_DEV double ppf(double q, const K& k) {
+    return ppf_bounds_cont(gammaincinv_p(k.alpha, q, k.lga) / k.beta, q, 0.0, kInf);
+  }
+  template <int FN> static M355_DEV double eval(double x, const K& k) {
+    if constexpr (FN == M355_LOGPDF) return logpdf(x, k);
+    if constexpr (FN == M355_PDF) return exp_(logpdf(x, k));        // gamma.py:44-45
+    if constexpr (FN == M355_LOGCDF) return logcdf(x, k);
+    if constexpr (FN == M355_LOGSF) return logsf(x, k);
+    if constexpr (FN == M355_CDF) return exp_(logcdf(x, k));        // gamma.py:40-41
+    if constexpr (FN == M355_SF) return 1.0 - exp_(logcdf(x, k));   // gamma.py:53-54
+    if constexpr (FN == M355_PPF) return ppf(x, k);
+    if constexpr (FN == M355_ISF) return ppf(1.0 - x, k);           // gamma.py:57-58
+    return kNaN;
+  }
+};
+
+// ----------------------------------------------------------------------------------------- beta
+template <> struct Dist<M355_BETA> {
+  static constexpr int NP = 2;
+  struct K {
+    double a, b, am1, bm1, lbeta;
+  };
+  static M355_HD K derive(const double* p) {
+    K k;
+    k.a = p[0];
+    k.b = p[1];
+    k.am1 = p[0] - 1.0;
+    k.bm1 = p[1] - 1.0;
+    // pytensor.tensor.special.betaln (lgamma(a)+lgamma(b)-lgamma(a+b)), cancellation-free form
+    k.lbeta = lbeta_(p[0], p[1]);
+    return k;
+  }
+  // beta.py:102-108; xlogy0(alpha+beta-1, 1) is a*log(1) == 0 (or the xlogy0 zero).
+  static M355_DEV double logpdf(double x, const K& k) {
+    const double t = xlogy0_l(k.am1, flog(x)) + xlogy0_l(k.bm1, flog(1.0 - x));
+    const double r = t - (0.0 + k.lbeta);
+    return ((x < 0.0) | (x > 1.0)) ? -kInf : r;
+  }
+  // beta.py:90-99
+  static M355_DEV double logcdf(double x, const K& k) {
+    if (x < 0.0) return -kInf;
+    if (x < 1.0) return flog(betainc_(k.a, k.b, x, k.lbeta));
+    return (x == x) ? 0.0 : 0.0;  // x >= 1 and NaN (all comparisons false) both select 0
+  }
+  // beta.py:111-120
+  static M355_DEV double logsf(double x, const K& k) {
+    if (x < 0.0) return 0.0;
+    if (x < 1.0) return flog(betainc_(k.b, k.a, 1.0 - x, k.lbeta));
+    return -kInf;
+  }
+  template <int FN> static M355_DEV double eval(double x, const K& k) {
+    if constexpr (FN == M355_LOGPDF) return logpdf(x, k);
+    if constexpr (FN == M355_PDF) return exp_(logpdf(x, k));  // beta.py:74-75
+    if constexpr (FN == M355_LOGCDF) return logcdf(x, k);
+    if constexpr (FN == M355_LOGSF) return logsf(x, k);
+    if constexpr (FN == M355_CDF) return exp_(logcdf(x, k));  // beta.py:66-67
+    if constexpr (FN == M355_SF) return exp_(logsf(x, k));    // beta.py:82-83
+    if constexpr (FN == M355_PPF || FN == M355_ISF) {         // beta.py:78-79, 70-71
+      const double q = (FN == M355_ISF) ? 1.0 - x : x;
+      return ppf_bounds_cont(betaincinv_(k.a, k.b, q, k.lbeta), q, 0.0, 1.0);
+    }
+    return kNaN;
+  }
+};
+
+// ------------------------------------------------------------------------------------- studentt
+template <> struct Dist<M355_STUDENTT> {
+  static constexpr int NP = 3;
+  struct K {
+    double nu, mu, sigma, c, hnp1, inv_s2nu, lbeta_h;  // lbeta_h = betaln(nu/2, 1/2)
+  };
+  static M355_HD K derive(const double* p) {
+    K k;
+    k.nu = p[0];
+    k.mu = p[1];
+    k.sigma = p[2];
+    const double lg_h = lgamma_(0.5 * p[0]);
+    const double lg_hp = lgamma_(0.5 * (p[0] + 1.0));
+    k.c = lg_hp - lg_h - 0.5 * flog(p[0] * kPi * p[2] * p[2]);
+    k.hnp1 = 0.5 * (p[0] + 1.0);
+    k.inv_s2nu = 1.0 / (p[2] * p[2] * p[0]);
+    k.lbeta_h = lbeta_(0.5 * p[0], 0.5);
+    return k;
+  }
+  // studentt.py:108-119.  The nu > 1e5 arm is normal.LOGCDF(x, mu, sigma): the reference binds
+  // `normal_logpdf` to normal.logcdf (studentt.py:8); reproduced as is (quirk Q1).
+  static M355_DEV double logpdf(double x, const K& k) {
+    if (k.nu > 1e5) return normal_logcdf_z((x - k.mu) / k.sigma);
+    const double d = x - k.mu;
+    return k.c - k.hnp1 * flog1p(d * d * k.inv_s2nu);
+  }
+  // studentt.py:100-105.  The nu > 1e5 arm is normal.CDF(z, mu, sigma) on the already
+  // standardised z (mis-import studentt.py:6); reproduced as is (quirk Q1).
+  static M355_DEV double logcdf_raw(double x, double mu, const K& k) {
+    const double z = (x - mu) / k.sigma;
+    if (k.nu > 1e5) return 0.5 * (1.0 + erf_((z - mu) / (k.sigma * kSqrt2)));
+    const double f = 0.5 * betainc_(0.5 * k.nu, 0.5, k.nu / (z * z + k.nu), k.lbeta_h);
+    return (z < 0.0) ? flog(f) : flog1p(-f);
+  }
+  static M355_DEV double ppf(double q, const K& k) {  // studentt.py:79-89
+    double r;
+    if (__builtin_fabs(q - 0.5) < 1e-14) {
+      r = 0.0;
+    } else {
+      const double qq = (q < 0.5) ? 2.0 * q : 2.0 * (1.0 - q);
+      const double b = betaincinv_(0.5 * k.nu, 0.5, qq, k.lbeta_h);
+      const double t = sqrt_(k.nu) * sqrt_(1.0 / b - 1.0);
+      r = (q < 0.5) ? -t : t;
+    }
+    return ppf_bounds_cont(k.mu + r * k.sigma, q, -kInf, kInf);
+  }
+  template <int FN> static M355_DEV double eval(double x, const K& k) {
+    if constexpr (FN == M355_LOGPDF) return logpdf(x, k);
+    if constexpr (FN == M355_PDF) return exp_(logpdf(x, k));               // studentt.py:75-76
+    if constexpr (FN == M355_LOGCDF) return logcdf_raw(x, k.mu, k);
+    if constexpr (FN == M355_LOGSF) return logcdf_raw(-x, -k.mu, k);       // studentt.py:122-123
+    if constexpr (FN == M355_CDF) return exp_(logcdf_raw(x, k.mu, k));     // studentt.py:67-68
+    if constexpr (FN == M355_SF) return exp_(logcdf_raw(-x, -k.mu, k));    // studentt.py:92-93
+    if constexpr (FN == M355_PPF) return ppf(x, k);
+    if constexpr (FN == M355_ISF) return ppf(1.0 - x, k);                  // studentt.py:71-72
+    return kNaN;
+  }
+};
+
+// -------------------------------------------------------------------------------------- poisson
+template <> struct Dist<M355_POISSON> {
+  static constexpr int NP = 1;
+  struct K {
+    double mu, logmu;
+  };
+  static M355_HD K derive(const double* p) {
+    K k;
+    k.mu = p[0];
+    k.logmu = flog(p[0]);
+    return k;
+  }
+  // poisson.py:70-71: no support switch; gammaln's poles give -inf at negative integers (Q6).
+  static M355_DEV double logpdf(double x, const K& k) {
+    return (xlogy0_l(x, k.logmu) - lgamma_(x + 1.0)) - k.mu;
+  }
+  static M355_DEV double cdf(double x, const K& k) {  // poisson.py:49-50
+    return cdf_bounds(gammainc_q(x + 1.0, k.mu, lgamma_(x + 1.0)), x, 0.0, kInf);
+  }
+  static M355_DEV double sf(double x, const K& k) {  // poisson.py:58-59
+    const double a = floor_(x) + 1.0;
+    return sf_bounds(gammainc_p(a, k.mu, lgamma_(a)), x, 0.0, kInf);
+  }
+  template <int FN> static M355_DEV double eval(double x, const K& k) {
+    if constexpr (FN == M355_LOGPDF) return logpdf(x, k);
+    if constexpr (FN == M355_PDF) return exp_(logpdf(x, k));  // poisson.py:45-46
+    if constexpr (FN == M355_CDF) return cdf(x, k);
+    if constexpr (FN == M355_SF) return sf(x, k);
+    if constexpr (FN == M355_LOGCDF) return flog(cdf(x, k));  // poisson.py:74-75
+    if constexpr (FN == M355_LOGSF) return flog(sf(x, k));    // poisson.py:78-79
+    return kNaN;
+  }
+};
+
+// ------------------------------------------------------------------------------------- binomial
+template <> struct Dist<M355_BINOMIAL> {
+  static constexpr int NP = 2;
+  struct K {
+    double n, p, lgn1, logp, log1mp;
+  };
+  static M355_HD K derive(const double* p) {
+    K k;
+    k.n = p[0];
+    k.p = p[1];
+    k.lgn1 = lgamma_(p[0] + 1.0);
+    k.logp = flog(p[1]);
+    k.log1mp = flog1p(-p[1]);
+    return k;
+  }
+  static M355_DEV double logpdf(double x, const K& k) {  // binomial.py:66-75
+    const double nmx = k.n - x;
+    double r = k.lgn1 - lgamma_(x + 1.0) - lgamma_(nmx + 1.0) + xlogy0_l(x, k.logp) + nmx * k.log1mp;
+    return ((x < 0.0) | (x > k.n)) ? -kInf : r;
+  }
+  static M355_DEV double cdf(double x, const K& k) {  // binomial.py:45-46
+    const double a = k.n - x, b = x + 1.0;
+    return cdf_bounds(betainc_(a, b, 1.0 - k.p, lbeta_(a, b)), x, 0.0, k.n);
+  }
+  template <int FN> static M355_DEV double eval(double x, const K& k) {
+    if constexpr (FN == M355_LOGPDF) return logpdf(x, k);
+    if constexpr (FN == M355_PDF) return exp_(logpdf(x, k));    // binomial.py:41-42
+    if constexpr (FN == M355_CDF) return cdf(x, k);
+    if constexpr (FN == M355_SF) return 1.0 - cdf(x, k);        // binomial.py:54-55
+    if constexpr (FN == M355_LOGCDF) return flog(cdf(x, k));    // binomial.py:78-79
+    if constexpr (FN == M355_LOGSF) return flog1p(-cdf(x, k));  // binomial.py:82-83
+    return kNaN;
+  }
+};
+
+// Which (dist, fn) pairs exist on the path (poisson/binomial ppf/isf use find_ppf_discrete:
+// SURVEY.md 8(f) rank 2, not built yet).
+constexpr bool supported(int dist, int fn) {
+  if (fn < 0 || fn > M355_ISF) return false;
+  if (dist == M355_POISSON || dist == M355_BINOMIAL) return fn != M355_PPF && fn != M355_ISF;
+  return dist >= M355_NORMAL && dist <= M355_BINOMIAL;
+}
+
+}  // namespace m355

@@ -1,0 +1,361 @@
+// Elementwise evaluation kernels (gfx950): the replacement for the fused Elemwise loop PyTensor
+// compiles for <dist>.<fn>(x, *params), plus the fused sum-logp epilogue.
+//
+// Three kernels per (dist, fn):
+//   k_scalar    x is a full contiguous array, every parameter a scalar (their derived constants
+//               are computed once on the host and arrive as kernel arguments).  Grid-stride over tiles of
+//               2048 elements; each thread issues kUnroll independent 16-byte loads (lane i at
+//               base + 16*i: one 1-KiB request per wavefront instruction) before it computes,
+//               and stores 16 bytes per lane the same way.  This is the HBM-bound metric path:
+//               16 B of traffic per element, nothing else touches memory.
+//   k_periodic  parameters of period P along the flat index (x of shape (R, P), params (P,)):
+//               each workgroup derives the P parameter-only constants once (lgamma, log, ...)
+//               into LDS as struct-of-arrays (conflict-free ds_read_b64) and then streams x as
+//               k_scalar does, keeping a running (index mod P) in 32-bit integer adds.
+//   k_generic   any other broadcast pattern (full-size parameter arrays, outer broadcast, scalar
+//               x, unaligned pointers): one element per thread per step, operands indexed by
+//               (i / div) % mod, constants derived per element.
+// With REDUCE the result is not stored: per-thread sums -> 64-lane shuffle reduction -> LDS ->
+// one double per workgroup in `partials`; k_final adds those in a fixed order (deterministic).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "m355_dists.h"
+
+namespace m355 {
+
+struct DevOperand {
+  const void* ptr;
+  double scalar;
+  unsigned long long div, mod;
+  int dtype;
+};
+
+struct LaunchArgs {
+  int fn;
+  int out_dtype;
+  long long n;
+  DevOperand x;
+  int nparams;
+  DevOperand p[3];
+  void* out;         // elementwise result (unused with partials)
+  double* partials;  // non-null: reduce, one double per workgroup
+  int* nblocks_out;  // receives the number of partials written
+  hipStream_t stream;
+};
+
+constexpr int kBlock = 256;
+constexpr int kUnroll = 4;
+constexpr int kVec = 2;
+constexpr int kTile = kBlock * kVec * kUnroll;  // 2048 elements = 16 KiB of f64 in, 16 KiB out
+constexpr int kMaxBlocks = 2048;                // 256 CUs x 8 workgroups
+constexpr int kMaxPeriodBytes = 64 * 1024;      // LDS table cap for k_periodic
+
+typedef double d2_t __attribute__((ext_vector_type(2)));
+typedef float f2_t __attribute__((ext_vector_type(2)));
+typedef long long l2_t __attribute__((ext_vector_type(2)));
+
+template <bool F64IO> M355_DEV void load2(const void* p, int dt, long long i, double& a, double& b) {
+  if (F64IO || dt == M355_F64) {
+    const d2_t v = *reinterpret_cast<const d2_t*>(static_cast<const double*>(p) + i);
+    a = v.x;
+    b = v.y;
+  } else if (dt == M355_F32) {
+    const f2_t v = *reinterpret_cast<const f2_t*>(static_cast<const float*>(p) + i);
+    a = (double)v.x;
+    b = (double)v.y;
+  } else {
+    const l2_t v = *reinterpret_cast<const l2_t*>(static_cast<const long long*>(p) + i);
+    a = (double)v.x;
+    b = (double)v.y;
+  }
+}
+template <bool F64IO> M355_DEV void store2(void* p, int dt, long long i, double a, double b) {
+  if (F64IO || dt == M355_F64) {
+    d2_t v;
+    v.x = a;
+    v.y = b;
+    *reinterpret_cast<d2_t*>(static_cast<double*>(p) + i) = v;
+  } else {
+    f2_t v;
+    v.x = (float)a;
+    v.y = (float)b;
+    *reinterpret_cast<f2_t*>(static_cast<float*>(p) + i) = v;
+  }
+}
+M355_DEV double load1(const void* p, int dt, unsigned long long i) {
+  if (dt == M355_F64) return static_cast<const double*>(p)[i];
+  if (dt == M355_F32) return (double)static_cast<const float*>(p)[i];
+  return (double)static_cast<const long long*>(p)[i];
+}
+M355_DEV void store1(void* p, int dt, long long i, double v) {
+  if (dt == M355_F64) static_cast<double*>(p)[i] = v;
+  else static_cast<float*>(p)[i] = (float)v;
+}
+
+// Sum over the workgroup; the result is valid in thread 0.
+M355_DEV double block_reduce_sum(double v) {
+  __shared__ double red[kBlock / 64];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    v = red[0];
+#pragma unroll
+    for (int w = 1; w < kBlock / 64; ++w) v += red[w];
+  }
+  return v;
+}
+
+template <int D, int FN, bool REDUCE, bool F64IO>
+__global__ __launch_bounds__(kBlock) void k_scalar(const void* __restrict__ x, int xdt,
+                                                   void* __restrict__ out, int odt, long long n,
+                                                   const typename Dist<D>::K k,
+                                                   double* __restrict__ partials) {
+  using DD = Dist<D>;
+  const long long ntiles = n / kTile;
+  double acc = 0.0;
+  for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const long long base = tile * kTile + threadIdx.x * kVec;
+    double v[kUnroll][kVec];
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) load2<F64IO>(x, xdt, base + u * (kBlock * kVec), v[u][0], v[u][1]);
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) {
+      v[u][0] = DD::template eval<FN>(v[u][0], k);
+      v[u][1] = DD::template eval<FN>(v[u][1], k);
+      if constexpr (REDUCE) {
+        acc += v[u][0] + v[u][1];
+      } else {
+        store2<F64IO>(out, odt, base + u * (kBlock * kVec), v[u][0], v[u][1]);
+      }
+    }
+  }
+  for (long long i = ntiles * kTile + (long long)blockIdx.x * kBlock + threadIdx.x; i < n;
+       i += (long long)gridDim.x * kBlock) {
+    const double r = DD::template eval<FN>(load1(x, xdt, i), k);
+    if constexpr (REDUCE) acc += r;
+    else store1(out, odt, i, r);
+  }
+  if constexpr (REDUCE) {
+    acc = block_reduce_sum(acc);
+    if (threadIdx.x == 0) partials[blockIdx.x] = acc;
+  }
+}
+
+struct PeriodicParams {
+  const double* ptr[3];  // NULL: scalar
+  double scalar[3];
+};
+
+template <int D, int FN, bool REDUCE, bool F64IO>
+__global__ __launch_bounds__(kBlock) void k_periodic(const void* __restrict__ x, int xdt,
+                                                     void* __restrict__ out, int odt, long long n,
+                                                     PeriodicParams pa, unsigned P,
+                                                     double* __restrict__ partials) {
+  using DD = Dist<D>;
+  using K = typename DD::K;
+  constexpr int NK = sizeof(K) / sizeof(double);
+  extern __shared__ double lds[];  // [NK][P]
+  for (unsigned j = threadIdx.x; j < P; j += kBlock) {
+    double pp[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) pp[q] = (q < DD::NP && pa.ptr[q]) ? pa.ptr[q][j] : pa.scalar[q];
+    const K k = DD::derive(pp);
+    const double* kd = reinterpret_cast<const double*>(&k);
+#pragma unroll
+    for (int f = 0; f < NK; ++f) lds[f * P + j] = kd[f];
+  }
+  __syncthreads();
+  auto fetch = [&](unsigned idx) {
+    K k;
+    double* kd = reinterpret_cast<double*>(&k);
+#pragma unroll
+    for (int f = 0; f < NK; ++f) kd[f] = lds[f * P + idx];
+    return k;
+  };
+  const long long ntiles = n / kTile;
+  // running (element index mod P) of this thread's first element in the current tile
+  unsigned idx0 = (unsigned)(((unsigned long long)blockIdx.x * kTile + threadIdx.x * kVec) % P);
+  const unsigned tile_step = (unsigned)(((unsigned long long)gridDim.x * kTile) % P);
+  const unsigned u_step = (unsigned)((kBlock * kVec) % P);
+  double acc = 0.0;
+  for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const long long base = tile * kTile + threadIdx.x * kVec;
+    double v[kUnroll][kVec];
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) load2<F64IO>(x, xdt, base + u * (kBlock * kVec), v[u][0], v[u][1]);
+    unsigned idx = idx0;
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) {
+      unsigned idx1 = idx + 1;
+      idx1 = idx1 >= P ? idx1 - P : idx1;
+      v[u][0] = DD::template eval<FN>(v[u][0], fetch(idx));
+      v[u][1] = DD::template eval<FN>(v[u][1], fetch(idx1));
+      if constexpr (REDUCE) {
+        acc += v[u][0] + v[u][1];
+      } else {
+        store2<F64IO>(out, odt, base + u * (kBlock * kVec), v[u][0], v[u][1]);
+      }
+      idx += u_step;
+      idx = idx >= P ? idx - P : idx;
+    }
+    idx0 += tile_step;
+    idx0 = idx0 >= P ? idx0 - P : idx0;
+  }
+  for (long long i = ntiles * kTile + (long long)blockIdx.x * kBlock + threadIdx.x; i < n;
+       i += (long long)gridDim.x * kBlock) {
+    const double r = DD::template eval<FN>(load1(x, xdt, i), fetch((unsigned)((unsigned long long)i % P)));
+    if constexpr (REDUCE) acc += r;
+    else store1(out, odt, i, r);
+  }
+  if constexpr (REDUCE) {
+    acc = block_reduce_sum(acc);
+    if (threadIdx.x == 0) partials[blockIdx.x] = acc;
+  }
+}
+
+struct GenericOps {
+  DevOperand x;
+  DevOperand p[3];
+};
+
+M355_DEV double fetch_operand(const DevOperand& o, unsigned long long i, bool small) {
+  if (o.ptr == nullptr) return o.scalar;
+  unsigned long long idx = i;
+  if (small) {
+    unsigned j = (unsigned)i;
+    if (o.div != 1) j /= (unsigned)o.div;
+    if (o.mod <= 0xffffffffull && j >= (unsigned)o.mod) j %= (unsigned)o.mod;
+    idx = j;
+  } else {
+    if (o.div != 1) idx /= o.div;
+    if (idx >= o.mod) idx %= o.mod;
+  }
+  return load1(o.ptr, o.dtype, idx);
+}
+
+template <int D, int FN, bool REDUCE>
+__global__ __launch_bounds__(kBlock) void k_generic(GenericOps ops, void* __restrict__ out, int odt,
+                                                    long long n, double* __restrict__ partials) {
+  using DD = Dist<D>;
+  const bool small = n <= 0xffffffffll;
+  double acc = 0.0;
+  for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < n; i += (long long)gridDim.x * kBlock) {
+    const double xv = fetch_operand(ops.x, (unsigned long long)i, small);
+    double pp[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+    for (int q = 0; q < DD::NP; ++q) pp[q] = fetch_operand(ops.p[q], (unsigned long long)i, small);
+    const double r = DD::template eval<FN>(xv, DD::derive(pp));
+    if constexpr (REDUCE) acc += r;
+    else store1(out, odt, i, r);
+  }
+  if constexpr (REDUCE) {
+    acc = block_reduce_sum(acc);
+    if (threadIdx.x == 0) partials[blockIdx.x] = acc;
+  }
+}
+
+inline bool aligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; }
+
+// Host-side selection of the kernel for one (dist, fn); returns a hipError_t as int.
+template <int D, int FN, bool REDUCE> int launch_fn(const LaunchArgs& a) {
+  using DD = Dist<D>;
+  const long long n = a.n;
+  const bool x_full = a.x.ptr != nullptr && a.x.div == 1 && a.x.mod >= (unsigned long long)n;
+  const size_t xal = a.x.dtype == M355_F32 ? 8 : 16, oal = a.out_dtype == M355_F32 ? 8 : 16;
+  const bool vec_ok = x_full && aligned(a.x.ptr, xal) && (REDUCE || aligned(a.out, oal));
+  // compile-time f64 load/store path for the headline functions; everything else (and f32 /
+  // int64 data) goes through the same kernels with a wave-uniform dtype switch per access
+  constexpr bool kFastIO = FN <= M355_PPF;
+  const bool f64io = kFastIO && a.x.dtype == M355_F64 && (REDUCE || a.out_dtype == M355_F64);
+  bool all_scalar = true, periodic_ok = true;
+  unsigned long long P = 0;
+  for (int q = 0; q < DD::NP; ++q) {
+    const DevOperand& o = a.p[q];
+    if (o.ptr == nullptr) continue;
+    all_scalar = false;
+    if (o.div != 1 || o.dtype != M355_F64 || (P != 0 && o.mod != P)) periodic_ok = false;
+    P = o.mod;
+  }
+  periodic_ok = periodic_ok && !all_scalar && P >= 1 && P < (unsigned long long)n &&
+                P * sizeof(typename DD::K) <= (size_t)kMaxPeriodBytes;
+  const long long tiles = n / kTile;
+  int blocks;
+  if (vec_ok && (all_scalar || periodic_ok)) {
+    blocks = (int)(tiles < 1 ? 1 : (tiles > kMaxBlocks ? kMaxBlocks : tiles));
+  } else {
+    const long long want = (n + kBlock - 1) / kBlock;
+    blocks = (int)(want < 1 ? 1 : (want > 4 * kMaxBlocks ? 4 * kMaxBlocks : want));
+  }
+  if (REDUCE && a.nblocks_out) *a.nblocks_out = blocks;
+  if (vec_ok && all_scalar) {
+    // parameter-only constants once, on the host; they reach the kernel as arguments (SGPRs)
+    const double pp[3] = {a.p[0].scalar, a.p[1].scalar, a.p[2].scalar};
+    const typename DD::K k = DD::derive(pp);
+    if (f64io) {
+      if constexpr (kFastIO)
+        hipLaunchKernelGGL((k_scalar<D, FN, REDUCE, true>), dim3(blocks), dim3(kBlock), 0, a.stream,
+                           a.x.ptr, a.x.dtype, a.out, a.out_dtype, n, k, a.partials);
+    } else {
+      hipLaunchKernelGGL((k_scalar<D, FN, REDUCE, false>), dim3(blocks), dim3(kBlock), 0, a.stream, a.x.ptr,
+                         a.x.dtype, a.out, a.out_dtype, n, k, a.partials);
+    }
+  } else if (vec_ok && periodic_ok) {
+    PeriodicParams pa;
+    for (int q = 0; q < 3; ++q) {
+      pa.ptr[q] = (q < DD::NP) ? static_cast<const double*>(a.p[q].ptr) : nullptr;
+      pa.scalar[q] = a.p[q].scalar;
+    }
+    const size_t lds = (size_t)P * sizeof(typename DD::K);
+    if (f64io) {
+      if constexpr (kFastIO)
+        hipLaunchKernelGGL((k_periodic<D, FN, REDUCE, true>), dim3(blocks), dim3(kBlock), lds, a.stream,
+                           a.x.ptr, a.x.dtype, a.out, a.out_dtype, n, pa, (unsigned)P, a.partials);
+    } else {
+      hipLaunchKernelGGL((k_periodic<D, FN, REDUCE, false>), dim3(blocks), dim3(kBlock), lds, a.stream,
+                         a.x.ptr, a.x.dtype, a.out, a.out_dtype, n, pa, (unsigned)P, a.partials);
+    }
+  } else {
+    GenericOps ops;
+    ops.x = a.x;
+    for (int q = 0; q < 3; ++q) ops.p[q] = a.p[q];
+    hipLaunchKernelGGL((k_generic<D, FN, REDUCE>), dim3(blocks), dim3(kBlock), 0, a.stream, ops, a.out,
+                       a.out_dtype, n, a.partials);
+  }
+  return (int)hipGetLastError();
+}
+
+template <int D, bool REDUCE> int launch_dist(const LaunchArgs& a) {
+  switch (a.fn) {
+    case M355_LOGPDF: return launch_fn<D, M355_LOGPDF, REDUCE>(a);
+    case M355_LOGCDF: return launch_fn<D, M355_LOGCDF, REDUCE>(a);
+    case M355_LOGSF: return launch_fn<D, M355_LOGSF, REDUCE>(a);
+    default: break;
+  }
+  if constexpr (!REDUCE) {
+    switch (a.fn) {
+      case M355_PDF: return launch_fn<D, M355_PDF, false>(a);
+      case M355_CDF: return launch_fn<D, M355_CDF, false>(a);
+      case M355_SF: return launch_fn<D, M355_SF, false>(a);
+      default: break;
+    }
+    if constexpr (supported(D, M355_PPF)) {
+      if (a.fn == M355_PPF) return launch_fn<D, M355_PPF, false>(a);
+      if (a.fn == M355_ISF) return launch_fn<D, M355_ISF, false>(a);
+    }
+  }
+  return -1000;  // unsupported (dist, fn)
+}
+
+}  // namespace m355
+
+// One translation unit per distribution defines these (keeps hipcc compile times parallel).
+int m355_launch_normal(const m355::LaunchArgs& a);
+int m355_launch_gamma(const m355::LaunchArgs& a);
+int m355_launch_beta(const m355::LaunchArgs& a);
+int m355_launch_studentt(const m355::LaunchArgs& a);
+int m355_launch_poisson(const m355::LaunchArgs& a);
+int m355_launch_binomial(const m355::LaunchArgs& a);

@@ -1,0 +1,479 @@
+// Special functions the reference reaches through PyTensor scalar ops:
+// gammainc / gammaincc / gammaincinv, betainc / betaincinv, and thin wrappers over the device
+// libm for erf/erfc/erfcx/erfinv/lgamma/exp.  Written from the published series and continued
+// fractions (DLMF 8.11.4, 8.9.2, 8.17.22; Stirling's series DLMF 5.11.1); every loop is bounded.
+// All functions are per-lane scalar code: lanes of a wavefront that need different trip counts
+// simply run masked, there is no cross-lane communication.
+#pragma once
+#include "m355_math.h"
+
+namespace m355 {
+
+constexpr double kPi = 3.14159265358979323846;
+constexpr double kEps = 1.1102230246251565e-16;  // 2^-53
+constexpr double kEuler = 0.57721566490153286061;
+constexpr double kMaxLog = 709.782712893384;
+constexpr double kMinLog = -745.13321910194122;
+
+#if defined(__HIPCC__)
+M355_DEV double exp_(double x) { return ::exp(x); }
+M355_DEV double expm1_(double x) { return ::expm1(x); }
+M355_HD_HEAVY double lgamma_(double x) { return ::lgamma(x); }
+M355_DEV double erf_(double x) { return ::erf(x); }
+M355_DEV double erfc_(double x) { return ::erfc(x); }
+M355_DEV double erfcx_(double x) { return ::erfcx(x); }
+M355_DEV double erfinv_(double x) { return ::erfinv(x); }
+M355_DEV double sqrt_(double x) { return __builtin_sqrt(x); }
+M355_DEV double floor_(double x) { return __builtin_floor(x); }
+#else
+M355_DEV double exp_(double x) { return std::exp(x); }
+M355_DEV double expm1_(double x) { return std::expm1(x); }
+M355_DEV double lgamma_(double x) { return std::lgamma(x); }
+M355_DEV double erf_(double x) { return std::erf(x); }
+M355_DEV double erfc_(double x) { return std::erfc(x); }
+M355_DEV double erfcx_(double x) { return kNaN; }   // device libm only; not host-tested
+M355_DEV double erfinv_(double x) { return kNaN; }  // device libm only; not host-tested
+M355_DEV double sqrt_(double x) { return std::sqrt(x); }
+M355_DEV double floor_(double x) { return std::floor(x); }
+#endif
+
+// ------------------------------------------------------------------------------------------------
+// log(1+u) - u.  Series form 2*atanh(s) - u with s = u/(2+u) while |s| stays inside the range of
+// log_core's polynomial, direct evaluation elsewhere (no cancellation there).
+M355_HD double log1pmx(double u) {
+  if (u > -0.29 && u < 0.41) {
+    const double s = fdiv(u, 2.0 + u);
+    const double t = s * s;
+    double p = 0x1.2b584aae78c14p-4;
+    p = __builtin_fma(p, t, 0x1.39fe606542dbap-4);
+    p = __builtin_fma(p, t, 0x1.7462b4ab2ef6cp-4);
+    p = __builtin_fma(p, t, 0x1.c71c62e5800a1p-4);
+    p = __builtin_fma(p, t, 0x1.2492492df148dp-3);
+    p = __builtin_fma(p, t, 0x1.99999999952e2p-3);
+    p = __builtin_fma(p, t, 0x1.5555555555558p-2);
+    const double R = 2.0 * t * p;  // log(1+u) = 2s + s*R
+    const double h = 0.5 * u * u;
+    return __builtin_fma(s, h + R, -h);
+  }
+  return flog1p(u) - u;
+}
+
+// Stirling remainder: lgamma(a) - [(a-1/2) log a - a + log(2 pi)/2], a >= 10 (error < 4e-17).
+M355_HD double stirling_corr(double a) {
+  const double r = rcp(a);
+  const double r2 = r * r;
+  double s = -3617.0 / 122400.0;
+  s = __builtin_fma(s, r2, 1.0 / 156.0);
+  s = __builtin_fma(s, r2, -691.0 / 360360.0);
+  s = __builtin_fma(s, r2, 1.0 / 1188.0);
+  s = __builtin_fma(s, r2, -1.0 / 1680.0);
+  s = __builtin_fma(s, r2, 1.0 / 1260.0);
+  s = __builtin_fma(s, r2, -1.0 / 360.0);
+  s = __builtin_fma(s, r2, 1.0 / 12.0);
+  return s * r;
+}
+
+// lgamma(1 + a) with relative accuracy for small a > 0 (Taylor: -gamma a + sum zeta(n)(-a)^n/n).
+M355_DEV double lgam1p(double a) {
+  if (a < 0.03125) {
+    double s = -0x1.3b1d971fc5985p-4;
+    s = __builtin_fma(s, a, 0x1.556ad63243bc4p-4);
+    s = __builtin_fma(s, a, -0x1.748c33114c6d6p-4);
+    s = __builtin_fma(s, a, 0x1.9a01e385d5f8fp-4);
+    s = __builtin_fma(s, a, -0x1.c806706d57db4p-4);
+    s = __builtin_fma(s, a, 0x1.010b36af86397p-3);
+    s = __builtin_fma(s, a, -0x1.2703a1dcea3aep-3);
+    s = __builtin_fma(s, a, 0x1.5b40cb100c306p-3);
+    s = __builtin_fma(s, a, -0x1.a8b9c17aa6149p-3);
+    s = __builtin_fma(s, a, 0x1.151322ac7d848p-2);
+    s = __builtin_fma(s, a, -0x1.9a4d55beab2d7p-2);
+    s = __builtin_fma(s, a, 0x1.a51a6625307d3p-1);
+    s = __builtin_fma(s, a, -kEuler);
+    return s * a;
+  }
+  return lgamma_(1.0 + a);
+}
+
+// betaln(a,b) = lgamma(a)+lgamma(b)-lgamma(a+b).  When the larger argument is >= 10 the difference
+// lgamma(l)-lgamma(s+l) is taken from Stirling's series term by term,
+//   -(l-1/2)*(log1p(u)-u) + u/2 - s*log(s+l) + S(l) - S(s+l),  u = s/l,
+// so that a small result is not the difference of two huge rounded lgamma values.
+M355_HD_HEAVY double lbeta_(double a, double b) {
+  const double s = a < b ? a : b, l = a < b ? b : a;
+  if (!(l >= 10.0)) return lgamma_(s) + lgamma_(l) - lgamma_(s + l);
+  const double u = fdiv(s, l);
+  const double d = -(l - 0.5) * log1pmx(u) + 0.5 * u - s * flog(s + l) + (stirling_corr(l) - stirling_corr(s + l));
+  return lgamma_(s) + d;
+}
+
+// ------------------------------------------------------------------------------------------------
+// log( x^a e^-x / Gamma(a) ), a > 0, 0 < x < inf.  For a >= 10 in Stirling form
+//   -a*phi((x-a)/a) + log(a/(2 pi))/2 - S(a),  phi(u) = u - log1p(u),
+// which has no cancellation near x ~ a; directly otherwise.  `lga` = lgamma(a).
+M355_DEV double log_gamma_kernel(double a, double x, double lga) {
+  if (a >= 10.0) {
+    const double u = fdiv(x - a, a);
+    // log1p(u) - u: series near x ~ a, log(x/a) - u elsewhere (1+u would round x away for x << a)
+    const double l = (u > -0.29 && u < 0.41) ? log1pmx(u) : flog(fdiv(x, a)) - u;
+    return __builtin_fma(a, l, 0.5 * flog(a * (0.5 / kPi)) - stirling_corr(a));
+  }
+  return a * flog(x) - x - lga;
+}
+
+constexpr int kMaxIter = 100000;
+
+// DLMF 8.11.4:  P(a,x) = x^a e^-x / Gamma(a+1) * sum_{n>=0} x^n / ((a+1)...(a+n)).
+M355_DEV_HEAVY double gammainc_series(double a, double x, double lga) {
+  const double lk = log_gamma_kernel(a, x, lga);
+  if (lk < kMinLog) return 0.0;
+  double term = 1.0, sum = 1.0, r = a;
+  for (int n = 0; n < kMaxIter; ++n) {
+    r += 1.0;
+    term *= fdiv(x, r);
+    sum += term;
+    if (term <= kEps * sum) break;
+  }
+  return sum * exp_(lk) / a;
+}
+
+// Legendre's continued fraction (DLMF 8.9.2) for Q(a,x), x > a or x > 1: forward recurrence of
+// numerators/denominators with rescaling.
+M355_DEV_HEAVY double gammaincc_cf(double a, double x, double lga) {
+  const double lk = log_gamma_kernel(a, x, lga);
+  if (lk < kMinLog) return 0.0;
+  constexpr double big = 4503599627370496.0, biginv = 2.22044604925031308085e-16;
+  double y = 1.0 - a, z = x + y + 1.0, c = 0.0;
+  double p2 = 1.0, q2 = x, p1 = x + 1.0, q1 = z * x;
+  double ans = fdiv(p1, q1);
+  for (int n = 0; n < kMaxIter; ++n) {
+    c += 1.0;
+    y += 1.0;
+    z += 2.0;
+    const double yc = y * c;
+    const double pk = p1 * z - p2 * yc;
+    const double qk = q1 * z - q2 * yc;
+    double t = 1.0;
+    if (qk != 0.0) {
+      const double r = fdiv(pk, qk);
+      t = __builtin_fabs(ans - r) ;
+      const bool done = t <= kEps * __builtin_fabs(r);
+      ans = r;
+      if (done) break;
+    }
+    p2 = p1;
+    p1 = pk;
+    q2 = q1;
+    q1 = qk;
+    if (__builtin_fabs(pk) > big) {
+      p2 *= biginv;
+      p1 *= biginv;
+      q2 *= biginv;
+      q1 *= biginv;
+    }
+  }
+  return ans * exp_(lk);
+}
+
+// Q(a,x) for small x and small a (where 1 - P cancels):
+//   Q = [1 - x^a/Gamma(1+a)] - x^a/Gamma(a) * sum_{n>=1} (-x)^n / (n! (a+n)).
+M355_DEV_HEAVY double gammaincc_series(double a, double x, double lga) {
+  double fac = 1.0, sum = 0.0;
+  for (int n = 1; n < kMaxIter; ++n) {
+    fac *= -x / (double)n;
+    const double term = fdiv(fac, a + (double)n);
+    sum += term;
+    if (__builtin_fabs(term) <= kEps * __builtin_fabs(sum)) break;
+  }
+  const double logx = flog(x);
+  const double t = -expm1_(a * logx - lgam1p(a));
+  return t - exp_(a * logx - lga) * sum;
+}
+
+// Regularised lower incomplete gamma P(a, x) (pt.gammainc).  lga = lgamma(a).
+M355_DEV double gammainc_q(double a, double x, double lga);
+M355_DEV double gammainc_p(double a, double x, double lga) {
+  if (!(x >= 0.0) || !(a >= 0.0)) return kNaN;  // negative or NaN
+  if (a == 0.0) return x > 0.0 ? 1.0 : kNaN;
+  if (x == 0.0) return 0.0;
+  if (a == kInf) return x == kInf ? kNaN : 0.0;
+  if (x == kInf) return 1.0;
+  if (x > 1.0 && x > a) return 1.0 - gammainc_q(a, x, lga);
+  return gammainc_series(a, x, lga);
+}
+
+// Regularised upper incomplete gamma Q(a, x) (pt.gammaincc).
+M355_DEV double gammainc_q(double a, double x, double lga) {
+  if (!(x >= 0.0) || !(a >= 0.0)) return kNaN;
+  if (a == 0.0) return x > 0.0 ? 0.0 : kNaN;
+  if (x == 0.0) return 1.0;
+  if (a == kInf) return x == kInf ? kNaN : 1.0;
+  if (x == kInf) return 0.0;
+  if (x > 1.1) {
+    return (x < a) ? 1.0 - gammainc_series(a, x, lga) : gammaincc_cf(a, x, lga);
+  }
+  if (x <= 0.5) {
+    return (-0.4 < a * flog(x)) ? gammaincc_series(a, x, lga) : 1.0 - gammainc_series(a, x, lga);
+  }
+  return (x * 1.1 < a) ? 1.0 - gammainc_series(a, x, lga) : gammaincc_series(a, x, lga);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Standard normal quantile used only to seed the root finders (|error| < 4.5e-4, A&S 26.2.23).
+M355_DEV double norm_quantile_guess(double p) {
+  const double pp = p < 0.5 ? p : 1.0 - p;
+  const double t = sqrt_(-2.0 * flog(pp));
+  const double v = t - fdiv(2.515517 + t * (0.802853 + t * 0.010328),
+                            1.0 + t * (1.432788 + t * (0.189269 + t * 0.001308)));
+  return p < 0.5 ? -v : v;
+}
+
+// Inverse of P(a, .) (pt.gammaincinv): safeguarded Halley iteration on the smaller tail.
+M355_DEV_HEAVY double gammaincinv_p(double a, double p, double lga) {
+  if (!(a > 0.0) || !(p >= 0.0) || !(p <= 1.0)) return kNaN;
+  if (p == 0.0) return 0.0;
+  if (p == 1.0) return kInf;
+  const bool upper = p > 0.5;
+  const double q = 1.0 - p;  // exact for p in [0.5, 1]
+  // --- initial guess
+  double x;
+  {
+    const double lg1 = lga + flog(a);  // lgamma(a+1)
+    // lower-tail power law  P ~ x^a / Gamma(a+1)
+    const double xs = exp_(fdiv(flog(p) + lg1, a));
+    if (a < 1.0 || xs < 0.1 * a) {
+      x = xs;
+      if (upper && a < 1.0) {
+        // upper tail for small a: Q ~ x^(a-1) e^-x / Gamma(a)
+        const double y = -(flog(q) + lga);
+        if (y > 1.0) x = y - (1.0 - a) * flog(y);
+      }
+    } else {
+      // Wilson-Hilferty
+      const double z = norm_quantile_guess(p);
+      const double w = 1.0 - fdiv(1.0, 9.0 * a) + z * fdiv(1.0, 3.0 * sqrt_(a));
+      x = a * w * w * w;
+      if (!(w > 0.0) || x < 1e-3 * a) x = xs;
+      if (upper) {
+        const double y = -(flog(q) + lga);
+        if (y > 3.0 * a + 20.0) x = y + (a - 1.0) * flog(y);
+      }
+    }
+    if (!(x > 0.0)) x = 1e-300;
+    if (!(x < kInf)) x = 1e300;
+  }
+  double lo = 0.0, hi = kInf, shrink = 0.25, grow = 4.0;
+  for (int it = 0; it < 200; ++it) {
+    double f, tail;  // f = P - p or q - Q: increasing in x either way
+    if (upper) {
+      tail = gammainc_q(a, x, lga);
+      f = q - tail;
+    } else {
+      tail = gammainc_p(a, x, lga);
+      f = tail - p;
+    }
+    if (f == 0.0) break;
+    if (f < 0.0) lo = x; else hi = x;
+    const double d = exp_(log_gamma_kernel(a, x, lga));  // x * |dP/dx|
+    double xn = -1.0;
+    if (d > 0.0 && d < kInf) {
+      if (!upper && p < 0.25 && tail > 0.0) {
+        // Newton on log P(log x): exact for the power-law tail P ~ x^a / Gamma(a+1)
+        xn = x * exp_(-fdiv(flog(fdiv(tail, p)) * tail, d));
+      } else if (upper && q < 0.25 && tail > 0.0) {
+        // Newton on log Q(x): near-exact for the exponential tail
+        xn = x + x * fdiv(flog(fdiv(tail, q)) * tail, d);
+      } else {
+        const double dx_rel = fdiv(f, d);                  // Newton step / x
+        const double curv = 0.5 * dx_rel * (a - 1.0 - x);  // Halley: f''/f' = (a-1)/x - 1
+        const double den = 1.0 - curv;
+        xn = x - x * ((den > 0.5 && den < 2.0) ? fdiv(dx_rel, den) : dx_rel);
+      }
+    }
+    if (!(xn > lo) || !(xn < hi)) {
+      if (hi == kInf) {
+        xn = (lo > 0.0 ? lo : x) * grow + 1.0;
+        grow *= grow;
+      } else if (lo == 0.0) {
+        xn = hi * shrink;
+        shrink *= shrink;
+      } else {
+        xn = (hi > 4.0 * lo) ? sqrt_(lo) * sqrt_(hi) : 0.5 * (lo + hi);
+      }
+      if (!(xn > lo) || !(xn < hi)) break;  // interval exhausted
+    }
+    const double dx = __builtin_fabs(xn - x);
+    x = xn;
+    if (dx <= 4.0 * kEps * x) break;
+  }
+  return x;
+}
+
+// ------------------------------------------------------------------------------------------------
+// log( x^a (1-x)^b / B(a,b) ) with y = 1 - x supplied separately (so that callers that know 1-x
+// exactly keep it).  lbeta = lgamma(a)+lgamma(b)-lgamma(a+b).
+M355_DEV double log_beta_kernel(double a, double b, double x, double y, double lbeta) {
+  return a * flog(x) + b * flog(y) - lbeta;
+}
+
+// Power series for I_x(a,b), good when b*x <= 1 and x <= 0.95 (DLMF 8.17.8 rearranged):
+//   I_x = x^a/B(a,b) * [ 1/a + sum_{n>=1} (1-b)(2-b)...(n-b) x^n / (n! (a+n)) ].
+M355_DEV_HEAVY double betainc_pseries(double a, double b, double x, double lbeta) {
+  const double ai = fdiv(1.0, a);
+  double t = (1.0 - b) * x;
+  double v = fdiv(t, a + 1.0);
+  const double t1 = v;
+  double s = 0.0, n = 2.0;
+  const double z = kEps * ai;
+  for (int it = 0; it < kMaxIter && __builtin_fabs(v) > z; ++it) {
+    const double u = fdiv((n - b) * x, n);
+    t *= u;
+    v = fdiv(t, a + n);
+    s += v;
+    n += 1.0;
+  }
+  s += t1;
+  s += ai;
+  const double lt = a * flog(x) - lbeta;
+  if (lt > -700.0 && lt < 700.0) return s * exp_(lt);
+  const double tl = lt + flog(s);
+  return (tl < kMinLog) ? 0.0 : exp_(tl);
+}
+
+// Continued fraction DLMF 8.17.22 by the modified Lentz algorithm; converges fast for
+// x < (a+1)/(a+b+2).  Returns the fraction value (without the x^a(1-x)^b/(a B) prefactor).
+M355_DEV_HEAVY double betainc_cf(double a, double b, double x) {
+  constexpr double tiny = 1e-300;
+  const double qab = a + b, qap = a + 1.0, qam = a - 1.0;
+  double c = 1.0;
+  double d = 1.0 - fdiv(qab * x, qap);
+  if (__builtin_fabs(d) < tiny) d = tiny;
+  d = rcp(d);
+  double h = d;
+  for (int m = 1; m < kMaxIter; ++m) {
+    const double dm = (double)m;
+    const double m2 = 2.0 * dm;
+    double aa = fdiv(dm * (b - dm) * x, (qam + m2) * (a + m2));
+    d = 1.0 + aa * d;
+    if (__builtin_fabs(d) < tiny) d = tiny;
+    c = 1.0 + fdiv(aa, c);
+    if (__builtin_fabs(c) < tiny) c = tiny;
+    d = rcp(d);
+    h *= d * c;
+    aa = -fdiv((a + dm) * (qab + dm) * x, (a + m2) * (qap + m2));
+    d = 1.0 + aa * d;
+    if (__builtin_fabs(d) < tiny) d = tiny;
+    c = 1.0 + fdiv(aa, c);
+    if (__builtin_fabs(c) < tiny) c = tiny;
+    d = rcp(d);
+    const double del = d * c;
+    h *= del;
+    if (__builtin_fabs(del - 1.0) <= 2.0 * kEps) break;
+  }
+  return h;
+}
+
+// Regularised incomplete beta I_x(a,b) (pt.betainc).  `y` must be 1-x; lbeta = betaln(a,b).
+M355_DEV_HEAVY double betainc_xy(double a, double b, double x, double y, double lbeta) {
+  if (!(a > 0.0) || !(b > 0.0) || !(x >= 0.0) || !(x <= 1.0)) return kNaN;
+  if (x == 0.0) return 0.0;
+  if (y == 0.0) return 1.0;  // (x may have rounded to 1 while y is still a tiny positive number)
+  if (b * x <= 1.0 && x <= 0.95) return betainc_pseries(a, b, x, lbeta);
+  bool flip = false;
+  if (x > fdiv(a + 1.0, a + b + 2.0)) {
+    flip = true;
+    double t = a; a = b; b = t;
+    t = x; x = y; y = t;
+  }
+  double r;
+  if (flip && b * x <= 1.0 && x <= 0.95) {
+    r = betainc_pseries(a, b, x, lbeta);
+  } else {
+    const double lk = log_beta_kernel(a, b, x, y, lbeta);
+    r = (lk < kMinLog) ? 0.0 : fdiv(exp_(lk) * betainc_cf(a, b, x), a);
+  }
+  if (flip) r = (r <= kEps) ? 1.0 - kEps : 1.0 - r;
+  return r;
+}
+M355_DEV double betainc_(double a, double b, double x, double lbeta) {
+  return betainc_xy(a, b, x, 1.0 - x, lbeta);
+}
+
+// Initial guess for I_x(a,b) = p, p <= 1/2 (power-law tail or A&S 26.5.22).
+M355_DEV double betaincinv_guess(double a, double b, double p, double lbeta) {
+  const double xs = exp_(fdiv(flog(p * a) + lbeta, a));  // I ~ x^a/(a B)
+  double x = xs;
+  if (a >= 1.0 && b >= 1.0) {
+    const double z = -norm_quantile_guess(p);
+    const double lam = (z * z - 3.0) / 6.0;
+    const double ta = fdiv(1.0, 2.0 * a - 1.0), tb = fdiv(1.0, 2.0 * b - 1.0);
+    const double hh = fdiv(2.0, ta + tb);
+    const double w = fdiv(z * sqrt_(hh + lam), hh) - (tb - ta) * (lam + 5.0 / 6.0 - fdiv(2.0, 3.0 * hh));
+    x = fdiv(a, a + b * exp_(2.0 * w));
+    if (!(x > 0.0) || !(x < 1.0) || xs < 0.05) x = xs;
+  }
+  return x;
+}
+
+// Inverse of I_.(a,b) (pytensor.tensor.math.betaincinv).  The iterate t is x when the root is
+// <= 1/2 and y = 1-x otherwise (full relative accuracy of whichever is small).  Safeguarded Newton/Halley, with Newton on log(tail) while the tail is far below 1.
+M355_DEV_HEAVY double betaincinv_(double a, double b, double p, double lbeta) {
+  if (!(a > 0.0) || !(b > 0.0) || !(p >= 0.0) || !(p <= 1.0)) return kNaN;
+  if (p == 0.0) return 0.0;
+  if (p == 1.0) return 1.0;
+  const bool rep_y = p > betainc_xy(a, b, 0.5, 0.5, lbeta);
+  // Equation: I_x(a,b) = p for p <= 1/2, else I_y(b,a) = 1-p (exact), so that the small tail
+  // keeps full relative accuracy; betainc_xy takes x and y separately, so either equation can
+  // be evaluated from either iterate.
+  const bool eq_c = p > 0.5;
+  const double target = eq_c ? 1.0 - p : p;
+  const bool natural = rep_y == eq_c;  // tail increases with t
+  double t;
+  {
+    // guess from whichever tail is <= 1/2, converted to the iterate's side
+    const bool gc = p > 0.5;
+    const double g = gc ? betaincinv_guess(b, a, 1.0 - p, lbeta) : betaincinv_guess(a, b, p, lbeta);
+    t = (gc == rep_y) ? g : 1.0 - g;
+    if (!(t > 0.0)) t = 1e-300;
+    if (!(t < 0.5)) t = 0.25;
+  }
+  double lo = 0.0, hi = 0.5, shrink = 0.25;
+  for (int it = 0; it < 200; ++it) {
+    const double x = rep_y ? 1.0 - t : t;
+    const double y = rep_y ? t : 1.0 - t;
+    const double tail = eq_c ? betainc_xy(b, a, y, x, lbeta) : betainc_xy(a, b, x, y, lbeta);
+    const double g = tail - target;
+    if (g == 0.0) break;
+    const double f = natural ? g : -g;  // increasing in t
+    if (f < 0.0) lo = t; else hi = t;
+    const double d = exp_(log_beta_kernel(a, b, x, y, lbeta));  // x (1-x) |dI/dx|
+    double tn = -1.0;
+    if (d > 0.0 && d < kInf) {
+      const double w = fdiv(d, x * y);  // |d tail / dt|
+      if (target < 0.25 && tail > 0.0) {
+        const double ls = flog(fdiv(tail, target)) * tail;
+        tn = natural ? t * exp_(-fdiv(ls, t * w)) : t + fdiv(ls, w);
+      } else {
+        const double nstep = fdiv(f, w);
+        double c2 = fdiv(a - 1.0, x) - fdiv(b - 1.0, y);  // I''/I' in x
+        c2 = rep_y ? -c2 : c2;
+        const double den = 1.0 - 0.5 * nstep * c2;
+        tn = t - ((den > 0.5 && den < 2.0) ? fdiv(nstep, den) : nstep);
+      }
+    }
+    if (!(tn > lo) || !(tn < hi)) {
+      if (lo == 0.0) {
+        tn = hi * shrink;
+        shrink *= shrink;
+      } else {
+        tn = (hi > 4.0 * lo) ? sqrt_(lo) * sqrt_(hi) : 0.5 * (lo + hi);
+      }
+      if (!(tn > lo) || !(tn < hi)) break;
+    }
+    const double dt = __builtin_fabs(tn - t);
+    t = tn;
+    if (dt <= 4.0 * kEps * t) break;
+  }
+  return rep_y ? 1.0 - t : t;
+}
+
+}  // namespace m355

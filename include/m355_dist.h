@@ -1,0 +1,112 @@
+/*
+ * m355_dist.h -- C-ABI of libm355dist.so, the MI355X (gfx950) evaluation path for
+ * pytensor_distributions' per-distribution functions.
+ *
+ * The reference has no FFI of its own: its "operator interface" for this path is the module-level
+ * function API (normal.logpdf(x, mu, sigma) ...), whose arithmetic PyTensor lowers to a fused
+ * Elemwise C loop / RandomVariable.perform / Blockwise LAPACK calls.  Each entry point below is what
+ * a PyTensor Op.perform (or any other host) binds instead of that loop; the reference lines it
+ * replaces are cited per entry point (paths relative to /root/reference/pytensor_distributions).
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative M355_ERR_* otherwise; the message of the
+ *     last failure on the calling thread is m355_last_error().  Nothing throws across the boundary.
+ *   - all data pointers are DEVICE pointers on the current HIP device; the caller owns every
+ *     buffer; `stream` is a hipStream_t passed as void* (NULL = the default stream).  Calls only
+ *     enqueue work: they never synchronise, and allocate nothing.
+ *   - an operand (x or a parameter) is described by m355_operand; element i of the flattened
+ *     broadcast result reads operand element (i / div) % mod:
+ *         scalar                : ptr == NULL, value in .scalar
+ *         full-size array       : div = 1, mod = n
+ *         inner-periodic (x of shape (R, C), parameter of shape (C,)) : div = 1, mod = C
+ *         outer (parameter of shape (R, 1))                         : div = C, mod = R
+ *     Parameter arrays are always float64; x may be float64, float32 or int64.
+ */
+#ifndef M355_DIST_H
+#define M355_DIST_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define M355_VERSION 100 /* 0.1.0 */
+
+enum m355_status {
+  M355_OK = 0,
+  M355_ERR_INVALID = -1,     /* bad argument (NULL pointer, n < 0, bad enum, bad operand) */
+  M355_ERR_UNSUPPORTED = -2, /* (dist, fn) pair not on the path */
+  M355_ERR_LAUNCH = -3,      /* HIP reported an error at launch */
+  M355_ERR_WORKSPACE = -4    /* workspace too small */
+};
+
+enum m355_dtype { M355_F64 = 0, M355_F32 = 1, M355_I64 = 2 };
+
+/* distribution ids: the reference module each one replaces */
+enum m355_dist {
+  M355_NORMAL = 0,   /* normal.py   */
+  M355_GAMMA = 1,    /* gamma.py    */
+  M355_BETA = 2,     /* beta.py     */
+  M355_STUDENTT = 3, /* studentt.py */
+  M355_POISSON = 4,  /* poisson.py  */
+  M355_BINOMIAL = 5  /* binomial.py */
+};
+
+/* function ids: the reference function of that module */
+enum m355_fn {
+  M355_LOGPDF = 0, /* normal.py:79-80 gamma.py:77-82 beta.py:102-108 studentt.py:108-119
+                      poisson.py:70-71 binomial.py:66-75 */
+  M355_LOGCDF = 1, /* normal.py:70-76 gamma.py:65-74 beta.py:90-99 studentt.py:100-105
+                      poisson.py:74-75 binomial.py:78-79 */
+  M355_LOGSF = 2,  /* normal.py:83-84 gamma.py:85-94 beta.py:111-120 studentt.py:122-123
+                      poisson.py:78-79 binomial.py:82-83 */
+  M355_PPF = 3,    /* normal.py:58-59 gamma.py:48-50 beta.py:78-79 studentt.py:79-89 (+helper.py:29-54) */
+  M355_PDF = 4,    /* normal.py:54-55 gamma.py:44-45 beta.py:74-75 studentt.py:75-76 ... */
+  M355_CDF = 5,    /* normal.py:46-47 gamma.py:40-41 beta.py:66-67 studentt.py:67-68
+                      poisson.py:49-50 binomial.py:45-46 (+helper.py:4-26) */
+  M355_SF = 6,     /* normal.py:62-63 gamma.py:53-54 beta.py:82-83 studentt.py:92-93
+                      poisson.py:58-59 binomial.py:54-55 (+helper.py:90-91) */
+  M355_ISF = 7     /* normal.py:50-51 gamma.py:57-58 beta.py:70-71 studentt.py:71-72 */
+};
+
+typedef struct m355_operand {
+  const void* ptr; /* device pointer, or NULL for a scalar */
+  double scalar;   /* value when ptr == NULL */
+  int64_t div;     /* see header comment; ignored for scalars */
+  int64_t mod;
+  int32_t dtype;   /* m355_dtype of *ptr (parameters: M355_F64 only) */
+  int32_t reserved;
+} m355_operand;
+
+int m355_version(void);
+const char* m355_last_error(void);
+/* Number of HIP devices visible to the library (hipGetDeviceCount). */
+int m355_device_count(void);
+
+/*
+ * out[i] = fn_dist(x[i], params...) for i in [0, n): replaces the fused Elemwise loop PyTensor
+ * compiles for <dist>.<fn>(x, *params) (functions cited at enum m355_fn).  `out_dtype` is
+ * M355_F64 or M355_F32.  Parameter order is the reference's (normal: mu, sigma; gamma: alpha,
+ * beta; beta: alpha, beta; studentt: nu, mu, sigma; poisson: mu; binomial: n, p).
+ */
+int m355_elemwise(int dist, int fn, int out_dtype, int64_t n, const m355_operand* x, int nparams,
+                  const m355_operand* params, void* out, void* stream);
+
+/*
+ * *out_sum = sum_i fn_dist(x[i], params...) in float64: replaces `pt.sum(<dist>.logpdf(...))`
+ * (no function of its own in the reference) without materialising the
+ * elementwise result.  Deterministic: per-thread partial sums -> wavefront shuffle reduction ->
+ * one partial per workgroup in `workspace` -> fixed-order final pass.  `workspace` is device
+ * memory of at least m355_sumlogp_workspace_bytes() bytes; out_sum is a device double.
+ */
+size_t m355_sumlogp_workspace_bytes(void);
+int m355_sumlogp(int dist, int fn, int64_t n, const m355_operand* x, int nparams,
+                 const m355_operand* params, double* out_sum, void* workspace,
+                 size_t workspace_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* M355_DIST_H */

@@ -1,0 +1,61 @@
+// Host (g++) build of the device scalar bodies, for CPU unit tests only: lets the series,
+// continued fractions and root finders of csrc/m355_special.h be checked against SciPy while no
+// GPU is attached.  The hardware seeds (v_rcp_f64, v_frexp_*) and the device libm (lgamma, exp,
+// erfc) are replaced by host equivalents, so this is NOT the parity test: parity is tests -m gpu.
+#include "../../distributions_amd/csrc/m355_dists.h"
+
+using namespace m355;
+
+template <int D, int FN>
+static void run(long n, const double* x, const double* p, double* out) {
+  const auto k = Dist<D>::derive(p);
+  for (long i = 0; i < n; ++i) out[i] = Dist<D>::template eval<FN>(x[i], k);
+}
+
+template <int D>
+static int by_fn(int fn, long n, const double* x, const double* p, double* out) {
+  switch (fn) {
+    case M355_LOGPDF: run<D, M355_LOGPDF>(n, x, p, out); return 0;
+    case M355_LOGCDF: run<D, M355_LOGCDF>(n, x, p, out); return 0;
+    case M355_LOGSF: run<D, M355_LOGSF>(n, x, p, out); return 0;
+    case M355_PPF: run<D, M355_PPF>(n, x, p, out); return 0;
+    case M355_PDF: run<D, M355_PDF>(n, x, p, out); return 0;
+    case M355_CDF: run<D, M355_CDF>(n, x, p, out); return 0;
+    case M355_SF: run<D, M355_SF>(n, x, p, out); return 0;
+    case M355_ISF: run<D, M355_ISF>(n, x, p, out); return 0;
+  }
+  return -1;
+}
+
+extern "C" int hm_eval(int dist, int fn, long n, const double* x, const double* p, double* out) {
+  switch (dist) {
+    case M355_NORMAL: return by_fn<M355_NORMAL>(fn, n, x, p, out);
+    case M355_GAMMA: return by_fn<M355_GAMMA>(fn, n, x, p, out);
+    case M355_BETA: return by_fn<M355_BETA>(fn, n, x, p, out);
+    case M355_STUDENTT: return by_fn<M355_STUDENTT>(fn, n, x, p, out);
+    case M355_POISSON: return by_fn<M355_POISSON>(fn, n, x, p, out);
+    case M355_BINOMIAL: return by_fn<M355_BINOMIAL>(fn, n, x, p, out);
+  }
+  return -1;
+}
+
+extern "C" void hm_log(long n, const double* x, double* out) { for (long i = 0; i < n; ++i) out[i] = flog(x[i]); }
+extern "C" void hm_log1p(long n, const double* x, double* out) { for (long i = 0; i < n; ++i) out[i] = flog1p(x[i]); }
+extern "C" void hm_gammainc(long n, const double* a, const double* x, double* out) {
+  for (long i = 0; i < n; ++i) out[i] = gammainc_p(a[i], x[i], lgamma_(a[i]));
+}
+extern "C" void hm_gammaincc(long n, const double* a, const double* x, double* out) {
+  for (long i = 0; i < n; ++i) out[i] = gammainc_q(a[i], x[i], lgamma_(a[i]));
+}
+extern "C" void hm_gammaincinv(long n, const double* a, const double* p, double* out) {
+  for (long i = 0; i < n; ++i) out[i] = gammaincinv_p(a[i], p[i], lgamma_(a[i]));
+}
+extern "C" void hm_betainc(long n, const double* a, const double* b, const double* x, double* out) {
+  for (long i = 0; i < n; ++i)
+    out[i] = betainc_(a[i], b[i], x[i], lbeta_(a[i], b[i]));
+}
+extern "C" void hm_betaincinv(long n, const double* a, const double* b, const double* p, double* out) {
+  for (long i = 0; i < n; ++i)
+    out[i] = betaincinv_(a[i], b[i], p[i], lbeta_(a[i], b[i]));
+}
+extern "C" void hm_lbeta(long n, const double* a, const double* b, double* out) { for (long i = 0; i < n; ++i) out[i] = lbeta_(a[i], b[i]); }

@@ -1,0 +1,210 @@
+"""CPU unit tests of the device scalar bodies (csrc/m355_dists.h, m355_special.h, m355_math.h)
+compiled for the host with g++ (tests/hostmath/hostmath.cpp).  These check the series, continued
+fractions and root finders against the oracle while no GPU is attached.  They are NOT the parity
+tests: the hardware seeds and the device libm differ on the GPU; parity proper is `-m gpu`."""
+
+import ctypes
+import os
+import subprocess
+import types
+
+import numpy as np
+import pytest
+from numpy.testing import assert_allclose
+from scipy import special as sp
+
+from oracle import restatement as R
+from tests import harness as H
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(HERE, "hostmath", "hostmath.cpp")
+LIB = os.path.join(HERE, "hostmath", "libhostmath.so")
+DIST = {"normal": 0, "gamma": 1, "beta": 2, "studentt": 3, "poisson": 4, "binomial": 5}
+FN = {"logpdf": 0, "logcdf": 1, "logsf": 2, "ppf": 3, "pdf": 4, "cdf": 5, "sf": 6, "isf": 7}
+_dp = ctypes.POINTER(ctypes.c_double)
+
+
+@pytest.fixture(scope="session")
+def hostlib():
+    csrc = os.path.join(HERE, "..", "distributions_amd", "csrc")
+    deps = [SRC] + [os.path.join(csrc, f) for f in ("m355_math.h", "m355_special.h", "m355_dists.h")]
+    if not os.path.exists(LIB) or any(os.path.getmtime(d) > os.path.getmtime(LIB) for d in deps):
+        subprocess.check_call(["g++", "-O2", "-mfma", "-std=c++17", "-shared", "-fPIC", "-o", LIB, SRC])
+    return ctypes.CDLL(LIB)
+
+
+def _ptr(a):
+    return a.ctypes.data_as(_dp)
+
+
+def host_namespace(lib, name, fns):
+    ns = types.SimpleNamespace()
+
+    def make(fn):
+        def call(x, *params):
+            x = np.ascontiguousarray(np.asarray(x, dtype=np.float64))
+            p = np.ascontiguousarray(np.asarray(params, dtype=np.float64))
+            out = np.empty_like(x)
+            rc = lib.hm_eval(DIST[name], FN[fn], ctypes.c_long(x.size), _ptr(x), _ptr(p), _ptr(out))
+            assert rc == 0
+            return out
+
+        return call
+
+    for fn in fns:
+        setattr(ns, fn, make(fn))
+    return ns
+
+
+def vec(lib, name, *arrs):
+    arrs = np.broadcast_arrays(*[np.asarray(a, dtype=np.float64) for a in arrs])
+    arrs = [np.ascontiguousarray(a).ravel() for a in arrs]
+    out = np.empty_like(arrs[0])
+    getattr(lib, name)(ctypes.c_long(out.size), *[_ptr(a) for a in arrs], _ptr(out))
+    return out
+
+
+HOST_FNS = {
+    "normal": ["logpdf", "pdf", "cdf"],  # erfcx / erfinv exist only in the device libm
+    "gamma": list(FN),
+    "beta": list(FN),
+    "studentt": list(FN),
+    "poisson": ["logpdf", "pdf", "cdf", "sf", "logcdf", "logsf"],
+    "binomial": ["logpdf", "pdf", "cdf", "sf", "logcdf", "logsf"],
+}
+
+
+@pytest.mark.parametrize("name, sp_dist, params, sp_params, support, kw", H.grids(), ids=H.grid_ids())
+def test_host_bodies_harness_a(hostlib, name, sp_dist, params, sp_params, support, kw):
+    H.run_distribution_checks(host_namespace(hostlib, name, HOST_FNS[name]), sp_dist, params,
+                              sp_params, support, **kw)
+
+
+def _close(got, exp, tol=1e-12):
+    """The parity criterion of BASELINE.md: |a-b| <= tol*max(1,|b|), NaN==NaN, inf==inf."""
+    got, exp = np.asarray(got), np.asarray(exp)
+    same = (got == exp) | (np.isnan(got) & np.isnan(exp))
+    with np.errstate(all="ignore"):
+        ok = same | (np.abs(got - exp) <= tol * np.maximum(1.0, np.abs(exp)))
+    return ok
+
+
+def test_host_log_log1p(hostlib):
+    rng = np.random.default_rng(0)
+    x = np.concatenate([np.exp(rng.uniform(-740, 700, 100000)), rng.uniform(0.5, 2, 100000),
+                        [1.0, 0.0, np.inf, -1.0, 5e-324, 1e-310, np.nan]])
+    with np.errstate(all="ignore"):
+        exp = np.log(x)
+    got = vec(hostlib, "hm_log", x)
+    assert np.all(_close(got, exp, 1e-15) | (np.abs(got - exp) <= 4e-16 * np.abs(exp)))
+    w = np.concatenate([rng.uniform(-1, 1, 100000), np.exp(rng.uniform(-50, 50, 50000)),
+                        -np.exp(rng.uniform(-50, 0, 50000)), [0, -1, np.inf, -2, np.nan]])
+    with np.errstate(all="ignore"):
+        exp = np.log1p(w)
+    got = vec(hostlib, "hm_log1p", w)
+    with np.errstate(all="ignore"):
+        assert np.all(_close(got, exp, 1e-15) | (np.abs(got - exp) <= 6e-16 * np.abs(exp)))
+
+
+@pytest.mark.parametrize("arange", [(1e-3, 1), (1, 10), (10, 100), (100, 1e4)])
+def test_host_gammainc(hostlib, arange):
+    rng = np.random.default_rng(1)
+    a = np.exp(rng.uniform(np.log(arange[0]), np.log(arange[1]), 20000))
+    x = a * np.exp(rng.normal(0, 1.0, a.size))
+    for name, f in (("hm_gammainc", sp.gammainc), ("hm_gammaincc", sp.gammaincc)):
+        got, exp = vec(hostlib, name, a, x), f(a, x)
+        # SciPy's own igam loses ~1e-11 for a > 100 far from the mean (checked against mpmath
+        # below, where these bodies hold 1e-12), so the SciPy comparison is looser there.
+        tol = 1e-12 if arange[1] <= 100 else 1e-10
+        m = exp > 1e-300  # subnormal results carry fewer bits
+        with np.errstate(all="ignore"):
+            assert np.all(_close(np.log(got[m]), np.log(exp[m]), tol)), name
+
+
+def test_host_gammainc_betainc_vs_mpmath(hostlib):
+    import mpmath as mp
+
+    mp.mp.dps = 40
+    rng = np.random.default_rng(11)
+    a = np.exp(rng.uniform(np.log(0.05), np.log(5e3), 60))
+    x = a * np.exp(rng.normal(0, 0.7, a.size))
+    gp, gq = vec(hostlib, "hm_gammainc", a, x), vec(hostlib, "hm_gammaincc", a, x)
+    for ai, xi, pi, qi in zip(a, x, gp, gq):
+        tp = mp.gammainc(ai, 0, xi, regularized=True)
+        tq = mp.gammainc(ai, xi, mp.inf, regularized=True)
+        if tp > 1e-290:
+            assert abs(mp.log(pi) - mp.log(tp)) <= 1e-12 * max(1, abs(mp.log(tp))), (ai, xi)
+        if tq > 1e-290:
+            assert abs(mp.log(qi) - mp.log(tq)) <= 1e-12 * max(1, abs(mp.log(tq))), (ai, xi)
+    a = np.exp(rng.uniform(np.log(0.05), np.log(300), 40))
+    b = np.exp(rng.uniform(np.log(0.05), np.log(300), 40))
+    xb = np.clip(rng.beta(np.minimum(a, 30) + 0.1, np.minimum(b, 30) + 0.1), 1e-12, 1 - 1e-12)
+    gi = vec(hostlib, "hm_betainc", a, b, xb)
+    for ai, bi, xi, ii in zip(a, b, xb, gi):
+        try:
+            t = mp.betainc(ai, bi, 0, xi, regularized=True)
+        except Exception:
+            continue  # mpmath's hypergeometric series fails to converge for some large a, b
+        if t > 1e-290:
+            assert abs(mp.log(ii) - mp.log(t)) <= 1e-12 * max(1, abs(mp.log(t))), (ai, bi, xi)
+
+
+def test_host_gammaincinv(hostlib):
+    rng = np.random.default_rng(2)
+    a = np.exp(rng.uniform(np.log(1e-2), np.log(1e4), 20000))
+    p = rng.uniform(0, 1, a.size)
+    p[:2000] = np.exp(rng.uniform(-300, 0, 2000))
+    p[2000:3000] = 1 - np.exp(rng.uniform(-36, 0, 1000))
+    got, exp = vec(hostlib, "hm_gammaincinv", a, p), sp.gammaincinv(a, p)
+    assert_allclose(got, exp, rtol=1e-12, atol=1e-300)  # subnormal roots carry fewer bits
+
+
+def test_host_betainc_and_inverse(hostlib):
+    rng = np.random.default_rng(3)
+    n = 20000
+    a = np.exp(rng.uniform(np.log(1e-2), np.log(500), n))
+    b = np.exp(rng.uniform(np.log(1e-2), np.log(500), n))
+    x = np.clip(rng.beta(np.minimum(a, 50) + 0.1, np.minimum(b, 50) + 0.1), 1e-300, 1 - 1e-16)
+    got, exp = vec(hostlib, "hm_betainc", a, b, x), sp.betainc(a, b, x)
+    with np.errstate(all="ignore"):
+        assert np.all(_close(np.log(got), np.log(exp)))
+    p = rng.uniform(1e-6, 1 - 1e-6, n)
+    got, exp = vec(hostlib, "hm_betaincinv", a, b, p), sp.betaincinv(a, b, p)
+    # SciPy's inverse clamps / fails for tiny roots, so the check is the forward equation itself:
+    # the residual may be the forward function's noise plus what 4 eps on the root's small side
+    # (and one rounding of x = 1 - y) move it through the slope dI/dx.
+    with np.errstate(all="ignore"):
+        slope = np.exp((a - 1) * np.log(got) + (b - 1) * np.log1p(-got) - sp.betaln(a, b))
+    allowed = 1e-12 * np.minimum(p, 1 - p) + slope * (9e-16 * np.minimum(got, 1 - got) + 2.3e-16)
+    resid = np.abs(sp.betainc(a, b, got) - p)
+    assert np.all(resid <= allowed), (a[resid > allowed][:5], b[resid > allowed][:5], p[resid > allowed][:5])
+    both = (exp > 1e-200) & (exp < 1 - 1e-12) & (np.abs(sp.betainc(a, b, exp) - p) <= allowed)
+    assert both.mean() > 0.9
+    assert_allclose(got[both], exp[both], rtol=1e-9)
+
+
+@pytest.mark.parametrize("name, sp_dist, params, sp_params, support, kw", H.grids(), ids=H.grid_ids())
+def test_host_bodies_vs_oracle_1e12(hostlib, name, sp_dist, params, sp_params, support, kw):
+    """Tight (1e-12) comparison with the oracle on a denser point set than harness A."""
+    rng = np.random.default_rng(7)
+    d = sp_dist(**sp_params)
+    xs = np.concatenate([np.asarray(d.rvs(2000, random_state=rng), dtype=np.float64),
+                         H.extended_vals(d, support)])
+    ns = host_namespace(hostlib, name, HOST_FNS[name])
+    for fn in HOST_FNS[name]:
+        if fn in ("ppf", "isf"):
+            pts = np.concatenate([rng.uniform(0, 1, 2000), H.ISF_POINTS, [1e-300, 1e-12, 1 - 1e-12]])
+        else:
+            pts = xs
+        with np.errstate(all="ignore"):
+            exp = R.TABLE[f"{name}_{fn}"](pts, *params)
+        got = getattr(ns, fn)(pts, *params)
+        ok = _close(got, exp)
+        if fn in ("ppf", "isf") and name in ("beta", "studentt"):
+            # the oracle's betaincinv (SciPy) returns NaN / clamps for extreme tails (SURVEY App. C,
+            # "version-dependent, unpinned"); studentt.ppf amplifies 1 ulp of betaincinv near the
+            # median through 1/x - 1 (reference formula, studentt.py:85-86)
+            with np.errstate(all="ignore"):
+                ok |= np.isnan(exp) | (np.abs(got - exp) <= 1e-9 * np.maximum(1.0, np.abs(exp)))
+            ok |= (pts < 1e-100) | (pts > 1 - 1e-15)
+        assert np.all(ok), (name, fn, params, pts[~ok][:5], got[~ok][:5], exp[~ok][:5])
