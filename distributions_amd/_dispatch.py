@@ -1,0 +1,209 @@
+"""Host side of the elementwise path: what PyTensor does symbolically around the fused Elemwise
+loop (NumPy-style broadcasting of (x, *params), dtype promotion, 0-d handling), done eagerly, then
+one call into the C-ABI.  `plan()` is pure Python (no GPU, no library) and is unit-tested on CPU.
+"""
+
+from __future__ import annotations
+
+import ctypes
+from dataclasses import dataclass, field
+from math import prod
+from typing import Any, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _lib
+from ._lib import DIST, F32, F64, FN, I64, NPARAMS, Operand
+
+
+# ------------------------------------------------------------------------------------------ plan
+@dataclass
+class OperandPlan:
+    kind: str  # "scalar" | "full" | "inner" | "outer" | "middle" | "expand"
+    div: int = 1
+    mod: int = 1
+
+
+@dataclass
+class Plan:
+    shape: Tuple[int, ...]
+    n: int
+    out_f32: bool
+    operands: List[OperandPlan] = field(default_factory=list)
+
+
+def _shape_of(a: Any) -> Tuple[int, ...]:
+    s = getattr(a, "shape", None)
+    return tuple(int(d) for d in s) if s is not None else ()
+
+
+def _dtype_name(a: Any) -> Optional[str]:
+    """'float32', 'int64', ... for arrays/tensors; None for Python scalars (weak)."""
+    dt = getattr(a, "dtype", None)
+    if dt is None:
+        return None
+    return str(dt).replace("torch.", "")
+
+
+def classify(op_shape: Sequence[int], out_shape: Sequence[int]) -> OperandPlan:
+    """How a broadcast operand is indexed by the flat output index i: (i // div) % mod."""
+    n = prod(out_shape)
+    size = prod(op_shape)
+    if size == 1:
+        return OperandPlan("scalar")
+    nd = len(out_shape)
+    s = (1,) * (nd - len(op_shape)) + tuple(op_shape)
+    if s == tuple(out_shape):
+        return OperandPlan("full", 1, n)
+    nz = [d for d in range(nd) if out_shape[d] != 1]  # dimensions that matter
+    match = [s[d] == out_shape[d] for d in nz]
+    first = match.index(True)
+    last = len(match) - 1 - match[::-1].index(True)
+    if all(match[first : last + 1]):
+        # one contiguous run of non-broadcast dimensions: index = (i // prod(trailing)) % size
+        div = prod(out_shape[d] for d in nz[last + 1 :])
+        kind = "inner" if div == 1 else ("outer" if first == 0 else "middle")
+        return OperandPlan(kind, div, size)
+    return OperandPlan("expand", 1, n)
+
+
+def plan(x: Any, params: Sequence[Any]) -> Plan:
+    """Broadcast shape, output dtype and per-operand index plan for (x, *params)."""
+    shapes = [_shape_of(a) for a in (x, *params)]
+    shape = tuple(np.broadcast_shapes(*shapes))
+    names = [_dtype_name(a) for a in (x, *params)]
+    floats = [nm for nm in names if nm is not None and nm.startswith(("float", "bfloat"))]
+    # float32 only if every floating *array* input is <= 32 bits (Python scalars are weak) and at
+    # least one exists; integer-only inputs give float64 (PyTensor upcasts int64 -> float64).
+    out_f32 = bool(floats) and all(nm in ("float32", "float16", "bfloat16") for nm in floats)
+    ints = [nm for nm in names if nm is not None and nm.startswith(("int", "uint")) and nm not in ("int8", "int16", "uint8")]
+    if ints:
+        out_f32 = False
+    return Plan(shape, prod(shape), out_f32, [classify(s, shape) for s in shapes])
+
+
+# ---------------------------------------------------------------------------------------- launch
+def _torch():
+    import torch
+
+    if not torch.cuda.is_available():
+        raise RuntimeError(
+            "distributions_amd needs a GPU: torch.cuda.is_available() is False and there is no CPU fallback"
+        )
+    return torch
+
+
+def _is_torch(a: Any) -> bool:
+    return type(a).__module__.startswith("torch")
+
+
+def _to_device(a: Any, torch, device, dtype):
+    if _is_torch(a):
+        t = a
+    else:
+        t = torch.from_numpy(np.ascontiguousarray(np.asarray(a)))
+    return t.to(device=device, dtype=dtype, non_blocking=False)
+
+
+def _x_dtype(a: Any, torch, out_f32: bool):
+    nm = _dtype_name(a)
+    if nm is None:
+        return torch.float64
+    if nm.startswith(("int", "uint", "bool")):
+        return torch.int64
+    if nm == "float64":
+        return torch.float64
+    return torch.float32 if out_f32 else torch.float64
+
+
+def _scalar_value(a: Any) -> float:
+    if _is_torch(a):
+        return float(a.reshape(-1)[0].item())
+    return float(np.asarray(a).reshape(-1)[0])
+
+
+def _device_of(args, torch):
+    for a in args:
+        if _is_torch(a) and a.is_cuda:
+            return a.device
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def _build_operands(pl: Plan, args: Sequence[Any], torch, device):
+    """Operand structs + the tensors that must stay alive until the launch is enqueued."""
+    keep = []
+    ops = (Operand * len(args))()
+    for j, (a, op) in enumerate(zip(args, pl.operands)):
+        o = ops[j]
+        o.reserved = 0
+        if op.kind == "scalar":
+            o.ptr, o.scalar, o.div, o.mod, o.dtype = None, _scalar_value(a), 1, 1, F64
+            continue
+        dt = _x_dtype(a, torch, pl.out_f32) if j == 0 else torch.float64
+        t = _to_device(a, torch, device, dt)
+        if op.kind == "expand":
+            t = t.expand(pl.shape)
+        t = t.contiguous()
+        keep.append(t)
+        o.ptr, o.scalar, o.div, o.mod = t.data_ptr(), 0.0, op.div, op.mod
+        o.dtype = {torch.float64: F64, torch.float32: F32, torch.int64: I64}[dt]
+    return ops, keep
+
+
+def _wants_torch(args) -> bool:
+    return any(_is_torch(a) for a in args)
+
+
+def elemwise(dist: str, fn: str, x: Any, *params: Any):
+    """<dist>.<fn>(x, *params) on the GPU.  Returns a torch CUDA tensor if any input was a torch
+    tensor, else a NumPy array (0-d inputs give a 0-d result), dtype float64 or float32."""
+    if len(params) != NPARAMS[dist]:
+        raise TypeError(f"{dist}.{fn} takes {NPARAMS[dist]} parameters, got {len(params)}")
+    torch = _torch()
+    L = _lib.lib()
+    args = (x, *params)
+    pl = plan(x, params)
+    device = _device_of(args, torch)
+    out_dt = torch.float32 if pl.out_f32 else torch.float64
+    with torch.cuda.device(device):
+        out = torch.empty(pl.n, dtype=out_dt, device=device)
+        if pl.n:
+            ops, keep = _build_operands(pl, args, torch, device)
+            stream = torch.cuda.current_stream(device).cuda_stream
+            rc = L.m355_elemwise(DIST[dist], FN[fn], F32 if pl.out_f32 else F64, pl.n,
+                                 ctypes.byref(ops[0]), len(params),
+                                 ctypes.cast(ctypes.byref(ops, ctypes.sizeof(Operand)), ctypes.POINTER(Operand)),
+                                 out.data_ptr(), stream)
+            _lib.check(rc)
+            del keep
+    out = out.reshape(pl.shape)
+    if _wants_torch(args):
+        return out
+    return out.cpu().numpy()
+
+
+def sumlogp(dist: str, fn: str, x: Any, *params: Any):
+    """sum(<dist>.<fn>(x, *params)) in float64 without materialising the elementwise result
+    (the reference spelling is pt.sum(dist.logpdf(...))).  Returns a 0-d torch
+    tensor on the device if any input was a torch tensor, else a Python float."""
+    if len(params) != NPARAMS[dist]:
+        raise TypeError(f"{dist}.{fn} takes {NPARAMS[dist]} parameters, got {len(params)}")
+    torch = _torch()
+    L = _lib.lib()
+    args = (x, *params)
+    pl = plan(x, params)
+    device = _device_of(args, torch)
+    with torch.cuda.device(device):
+        out = torch.empty(1, dtype=torch.float64, device=device)
+        ws_bytes = int(L.m355_sumlogp_workspace_bytes())
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=device)
+        ops, keep = _build_operands(pl, args, torch, device)
+        stream = torch.cuda.current_stream(device).cuda_stream
+        rc = L.m355_sumlogp(DIST[dist], FN[fn], pl.n, ctypes.byref(ops[0]), len(params),
+                            ctypes.cast(ctypes.byref(ops, ctypes.sizeof(Operand)), ctypes.POINTER(Operand)),
+                            out.data_ptr(), ws.data_ptr(), ws_bytes, stream)
+        _lib.check(rc)
+        del keep
+    if _wants_torch(args):
+        return out.reshape(())
+    return float(out.item())

@@ -1,0 +1,67 @@
+"""ctypes binding of libm355dist.so (C-ABI declared in include/m355_dist.h).
+
+There is no CPU fallback: if the shared library is missing, or no GPU is visible, every call
+raises.  PyTorch is used only to own device buffers and to name the current HIP stream.
+"""
+
+from __future__ import annotations
+
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libm355dist.so")
+
+F64, F32, I64 = 0, 1, 2
+DIST = {"normal": 0, "gamma": 1, "beta": 2, "studentt": 3, "poisson": 4, "binomial": 5}
+FN = {"logpdf": 0, "logcdf": 1, "logsf": 2, "ppf": 3, "pdf": 4, "cdf": 5, "sf": 6, "isf": 7}
+NPARAMS = {"normal": 2, "gamma": 2, "beta": 2, "studentt": 3, "poisson": 1, "binomial": 2}
+
+
+class Operand(ctypes.Structure):
+    _fields_ = [
+        ("ptr", ctypes.c_void_p),
+        ("scalar", ctypes.c_double),
+        ("div", ctypes.c_int64),
+        ("mod", ctypes.c_int64),
+        ("dtype", ctypes.c_int32),
+        ("reserved", ctypes.c_int32),
+    ]
+
+
+class M355Error(RuntimeError):
+    """A libm355dist.so entry point returned a non-zero status."""
+
+
+_lib = None
+
+
+def lib():
+    """Load libm355dist.so (once).  Raises if it has not been built: run
+    `python -c "import __graft_entry__ as g; g.build()"` or `make -C distributions_amd/csrc`."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: the HIP library has not been built "
+            "(make -C distributions_amd/csrc).  There is no CPU fallback."
+        )
+    L = ctypes.CDLL(LIB_PATH)
+    vp, i32, i64, sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_size_t
+    op = ctypes.POINTER(Operand)
+    L.m355_version.restype = i32
+    L.m355_last_error.restype = ctypes.c_char_p
+    L.m355_device_count.restype = i32
+    L.m355_elemwise.restype = i32
+    L.m355_elemwise.argtypes = [i32, i32, i32, i64, op, i32, op, vp, vp]
+    L.m355_sumlogp_workspace_bytes.restype = sz
+    L.m355_sumlogp.restype = i32
+    L.m355_sumlogp.argtypes = [i32, i32, i64, op, i32, op, vp, vp, sz, vp]
+    _lib = L
+    return L
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        raise M355Error(f"libm355dist status {rc}: {lib().m355_last_error().decode()}")

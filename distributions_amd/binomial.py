@@ -1,0 +1,39 @@
+"""Binomial distribution: same function API as the reference's binomial.py, evaluated by the HIP
+elementwise kernels (csrc/m355_elemwise.h, bodies in csrc/m355_dists.h)."""
+
+from ._dispatch import elemwise as _elemwise
+from ._dispatch import sumlogp as _sumlogp
+
+def logpdf(x, n, p):
+    """binomial.py:66-75 of the reference."""
+    return _elemwise("binomial", "logpdf", x, n, p)
+
+
+def logcdf(x, n, p):
+    """binomial.py:78-79 of the reference."""
+    return _elemwise("binomial", "logcdf", x, n, p)
+
+
+def logsf(x, n, p):
+    """binomial.py:82-83 of the reference."""
+    return _elemwise("binomial", "logsf", x, n, p)
+
+
+def pdf(x, n, p):
+    """binomial.py:41-42 of the reference."""
+    return _elemwise("binomial", "pdf", x, n, p)
+
+
+def cdf(x, n, p):
+    """binomial.py:45-46 of the reference."""
+    return _elemwise("binomial", "cdf", x, n, p)
+
+
+def sf(x, n, p):
+    """binomial.py:54-55 of the reference."""
+    return _elemwise("binomial", "sf", x, n, p)
+
+
+def sum_logpdf(x, n, p):
+    """sum(logpdf(x, n, p)) fused in one pass (the reference spells it pt.sum(logpdf(...)))."""
+    return _sumlogp("binomial", "logpdf", x, n, p)

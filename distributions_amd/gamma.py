@@ -1,0 +1,49 @@
+"""Gamma distribution: same function API as the reference's gamma.py, evaluated by the HIP
+elementwise kernels (csrc/m355_elemwise.h, bodies in csrc/m355_dists.h)."""
+
+from ._dispatch import elemwise as _elemwise
+from ._dispatch import sumlogp as _sumlogp
+
+def logpdf(x, alpha, beta):
+    """gamma.py:77-82 of the reference."""
+    return _elemwise("gamma", "logpdf", x, alpha, beta)
+
+
+def logcdf(x, alpha, beta):
+    """gamma.py:65-74 of the reference."""
+    return _elemwise("gamma", "logcdf", x, alpha, beta)
+
+
+def logsf(x, alpha, beta):
+    """gamma.py:85-94 of the reference."""
+    return _elemwise("gamma", "logsf", x, alpha, beta)
+
+
+def pdf(x, alpha, beta):
+    """gamma.py:44-45 of the reference."""
+    return _elemwise("gamma", "pdf", x, alpha, beta)
+
+
+def cdf(x, alpha, beta):
+    """gamma.py:40-41 of the reference."""
+    return _elemwise("gamma", "cdf", x, alpha, beta)
+
+
+def sf(x, alpha, beta):
+    """gamma.py:53-54 of the reference."""
+    return _elemwise("gamma", "sf", x, alpha, beta)
+
+
+def ppf(q, alpha, beta):
+    """gamma.py:48-50 of the reference."""
+    return _elemwise("gamma", "ppf", q, alpha, beta)
+
+
+def isf(q, alpha, beta):
+    """gamma.py:57-58 of the reference."""
+    return _elemwise("gamma", "isf", q, alpha, beta)
+
+
+def sum_logpdf(x, alpha, beta):
+    """sum(logpdf(x, alpha, beta)) fused in one pass (the reference spells it pt.sum(logpdf(...)))."""
+    return _sumlogp("gamma", "logpdf", x, alpha, beta)

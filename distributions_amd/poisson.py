@@ -1,0 +1,39 @@
+"""Poisson distribution: same function API as the reference's poisson.py, evaluated by the HIP
+elementwise kernels (csrc/m355_elemwise.h, bodies in csrc/m355_dists.h)."""
+
+from ._dispatch import elemwise as _elemwise
+from ._dispatch import sumlogp as _sumlogp
+
+def logpdf(x, mu):
+    """poisson.py:70-71 of the reference."""
+    return _elemwise("poisson", "logpdf", x, mu)
+
+
+def logcdf(x, mu):
+    """poisson.py:74-75 of the reference."""
+    return _elemwise("poisson", "logcdf", x, mu)
+
+
+def logsf(x, mu):
+    """poisson.py:78-79 of the reference."""
+    return _elemwise("poisson", "logsf", x, mu)
+
+
+def pdf(x, mu):
+    """poisson.py:45-46 of the reference."""
+    return _elemwise("poisson", "pdf", x, mu)
+
+
+def cdf(x, mu):
+    """poisson.py:49-50 of the reference."""
+    return _elemwise("poisson", "cdf", x, mu)
+
+
+def sf(x, mu):
+    """poisson.py:58-59 of the reference."""
+    return _elemwise("poisson", "sf", x, mu)
+
+
+def sum_logpdf(x, mu):
+    """sum(logpdf(x, mu)) fused in one pass (the reference spells it pt.sum(logpdf(...)))."""
+    return _sumlogp("poisson", "logpdf", x, mu)

@@ -1,0 +1,54 @@
+"""Allocation-free launch helpers over the C-ABI for callers that own their device buffers
+(benchmarks, sharded log-likelihood loops): x and out are contiguous torch CUDA tensors, parameters
+are Python scalars.  Work is enqueued on torch's current stream; nothing synchronises."""
+
+from __future__ import annotations
+
+import ctypes
+
+from . import _lib
+from ._lib import DIST, F32, F64, FN, I64, Operand
+
+
+def _dt(t, torch):
+    return {torch.float64: F64, torch.float32: F32, torch.int64: I64}[t.dtype]
+
+
+def _operands(x, params, torch):
+    ops = (Operand * (1 + len(params)))()
+    ops[0].ptr, ops[0].scalar, ops[0].div, ops[0].mod, ops[0].dtype = x.data_ptr(), 0.0, 1, x.numel(), _dt(x, torch)
+    for j, p in enumerate(params, start=1):
+        ops[j].ptr, ops[j].scalar, ops[j].div, ops[j].mod, ops[j].dtype = None, float(p), 1, 1, F64
+    return ops
+
+
+def _p(ops, j):
+    return ctypes.cast(ctypes.byref(ops, j * ctypes.sizeof(Operand)), ctypes.POINTER(Operand))
+
+
+def elemwise_into(dist: str, fn: str, x, params, out) -> None:
+    import torch
+
+    assert x.is_cuda and out.is_cuda and x.is_contiguous() and out.is_contiguous()
+    assert out.numel() == x.numel() and out.dtype in (torch.float64, torch.float32)
+    ops = _operands(x, params, torch)
+    stream = torch.cuda.current_stream(x.device).cuda_stream
+    _lib.check(_lib.lib().m355_elemwise(DIST[dist], FN[fn], _dt(out, torch), x.numel(), _p(ops, 0),
+                                        len(params), _p(ops, 1), out.data_ptr(), stream))
+
+
+def sumlogp_workspace(device):
+    import torch
+
+    return torch.empty(int(_lib.lib().m355_sumlogp_workspace_bytes()), dtype=torch.uint8, device=device)
+
+
+def sumlogp_into(dist: str, fn: str, x, params, out_sum, workspace) -> None:
+    """out_sum: float64 CUDA tensor; the total goes to out_sum[0] (pass a slice for other slots)."""
+    import torch
+
+    assert x.is_cuda and x.is_contiguous() and out_sum.dtype == torch.float64 and out_sum.is_cuda
+    ops = _operands(x, params, torch)
+    stream = torch.cuda.current_stream(x.device).cuda_stream
+    _lib.check(_lib.lib().m355_sumlogp(DIST[dist], FN[fn], x.numel(), _p(ops, 0), len(params), _p(ops, 1),
+                                       out_sum.data_ptr(), workspace.data_ptr(), workspace.numel(), stream))

@@ -104,3 +104,21 @@ def grids():
 
 def grid_ids():
     return [f"{name}-{'-'.join(str(v) for v in params)}" for name, _, params, _, _, _ in grids()]
+
+
+def close(got, exp, tol=1e-12):
+    """Parity criterion of BASELINE.md / SURVEY.md 8(d): |a-b| <= tol*max(1,|b|); NaN matches NaN,
+    +-inf must match exactly.  Returns the boolean mask."""
+    got, exp = np.asarray(got, dtype=np.float64), np.asarray(exp, dtype=np.float64)
+    same = (got == exp) | (np.isnan(got) & np.isnan(exp))
+    with np.errstate(all="ignore"):
+        return same | (np.abs(got - exp) <= tol * np.maximum(1.0, np.abs(exp)))
+
+
+def ppf_unpinned(name, fn, pts):
+    """Points where the oracle's own inverse (SciPy betaincinv) is known to clamp or return NaN
+    ('version-dependent, unpinned'): extreme tails of beta/studentt ppf."""
+    if fn in ("ppf", "isf") and name in ("beta", "studentt"):
+        q = 1.0 - pts if fn == "isf" else pts
+        return (q < 1e-100) | (q > 1 - 1e-15)
+    return np.zeros(np.shape(pts), dtype=bool)

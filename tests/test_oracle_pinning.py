@@ -138,3 +138,19 @@ def test_oracle_edge_table_survey_appendix_c():
                     [-inf, -3.56675, -1.32115, -1.41598, -12.0397, -inf, -inf], rtol=1e-5)
     # quirk Q2: gamma(alpha=1) at 0 and +inf
     assert_allclose(R.gamma_logpdf(np.array([0.0, inf]), 1.0, 1.0), [0.0, -inf])
+
+
+def test_oracle_c_leg_matches_restatement():
+    """oracle/elemwise_c.c (bench.py's cpu_baseline) against oracle/restatement.py."""
+    from oracle import c_leg
+
+    L = c_leg.load()
+    rng = np.random.default_rng(3)
+    for name, p, x in (("normal", (0.3, 1.7), rng.normal(0, 1, 5000)),
+                       ("gamma", (2.5, 1.3), rng.gamma(2.5, 1 / 1.3, 5000)),
+                       ("gamma", (1.0, 1.0), np.array([0.0, 1.0, np.inf, -1.0])),
+                       ("beta", (2.0, 5.0), np.concatenate([rng.beta(2, 5, 5000), [0.0, 1.0, -0.5, 1.5]]))):
+        with np.errstate(all="ignore"):
+            exp = R.TABLE[f"{name}_logpdf"](x, *p)
+            got = c_leg.logpdf(L, name, x, *p)
+        assert np.all(H.close(got, exp)), name
