@@ -131,7 +131,7 @@ int m355_elemwise(int dist, int fn, int out_dtype, int64_t n, const m355_operand
   return check_launch(dispatch(dist, a));
 }
 
-size_t m355_sumlogp_workspace_bytes(void) { return (size_t)4 * m355::kMaxBlocks * sizeof(double); }
+size_t m355_sumlogp_workspace_bytes(void) { return (size_t)m355::kMaxBlocks * sizeof(double); }
 
 int m355_sumlogp(int dist, int fn, int64_t n, const m355_operand* x, int nparams,
                  const m355_operand* params, double* out_sum, void* workspace, size_t workspace_bytes,

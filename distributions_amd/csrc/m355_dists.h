@@ -92,7 +92,7 @@ template <> struct Dist<M355_GAMMA> {
   }
   // gamma.py:77-82 with (alpha-1)*log(x) as xlogy0 (quirk Q2).
   static M355_DEV double logpdf(double x, const K& k) {
-    const double t = xlogy0_l(k.am1, flog(x));
+    const double t = xlogy0_l(k.am1, flog_stream(x));
     const double r = (t - x * k.beta) + k.c;
     return (x < 0.0) ? -kInf : r;
   }
@@ -153,7 +153,7 @@ template <> struct Dist<M355_BETA> {
   }
   // beta.py:102-108; xlogy0(alpha+beta-1, 1) is a*log(1) == 0 (or the xlogy0 zero).
   static M355_DEV double logpdf(double x, const K& k) {
-    const double t = xlogy0_l(k.am1, flog(x)) + xlogy0_l(k.bm1, flog(1.0 - x));
+    const double t = xlogy0_l(k.am1, flog_stream(x)) + xlogy0_l(k.bm1, flog_stream(1.0 - x));
     const double r = t - (0.0 + k.lbeta);
     return ((x < 0.0) | (x > 1.0)) ? -kInf : r;
   }
@@ -208,7 +208,7 @@ template <> struct Dist<M355_STUDENTT> {
   static M355_DEV double logpdf(double x, const K& k) {
     if (k.nu > 1e5) return normal_logcdf_z((x - k.mu) / k.sigma);
     const double d = x - k.mu;
-    return k.c - k.hnp1 * flog1p(d * d * k.inv_s2nu);
+    return k.c - k.hnp1 * flog1p_stream(d * d * k.inv_s2nu);
   }
   // studentt.py:100-105.  The nu > 1e5 arm is normal.CDF(z, mu, sigma) on the already
   // standardised z (mis-import studentt.py:6); reproduced as is (quirk Q1).

@@ -117,6 +117,71 @@ M355_HD double flog_pos(double x) {
   return __builtin_fma(ef, kLn2Hi, r);
 }
 
+// Keeps a polynomial coefficient in a scalar register pair: without this the compiler
+// rematerialises every 64-bit literal with two v_mov_b32 per use (7 fp64-op equivalents per log).
+#if defined(__HIP_DEVICE_COMPILE__)
+M355_DEV double sconst(double v) {
+  asm("" : "+s"(v));
+  return v;
+}
+#else
+M355_HD double sconst(double v) { return v; }
+#endif
+
+// n/d with NR Newton steps on the hardware seed and an optional residual correction.
+template <int NR, bool CORR> M355_HD double fdiv_t(double n, double d) {
+  double r = hw_rcp(d);
+#pragma unroll
+  for (int i = 0; i < NR; ++i) {
+    const double e = __builtin_fma(-d, r, 1.0);
+    r = __builtin_fma(e, r, r);
+  }
+  double q = n * r;
+  if (CORR) q = __builtin_fma(__builtin_fma(-q, d, n), r, q);
+  return q;
+}
+
+// Streaming log: exponent/mantissa split with 32-bit integer ops on the high word (half the issue
+// cost of fp64 instructions), one wave-rare branch to flog() for zero / subnormal / negative /
+// inf / NaN inputs.  Same polynomial as log_core.
+template <int NR, bool CORR> M355_HD double flog_fast_t(double x) {
+  const unsigned long long bits = __builtin_bit_cast(unsigned long long, x);
+  unsigned hx = (unsigned)(bits >> 32);
+  if ((hx - 0x00100000u) >= 0x7fe00000u) return flog(x);
+  hx += 0x3ff00000u - 0x3fe6a09eu;
+  const int k = (int)(hx >> 20) - 0x3ff;
+  hx = (hx & 0x000fffffu) + 0x3fe6a09eu;
+  const double m = __builtin_bit_cast(double, ((unsigned long long)hx << 32) | (bits & 0xffffffffull));
+  const double s = fdiv_t<NR, CORR>(m - 1.0, m + 1.0);
+  const double t = s * s;
+  double p = sconst(0x1.2b584aae78c14p-4);
+  p = __builtin_fma(p, t, sconst(0x1.39fe606542dbap-4));
+  p = __builtin_fma(p, t, sconst(0x1.7462b4ab2ef6cp-4));
+  p = __builtin_fma(p, t, sconst(0x1.c71c62e5800a1p-4));
+  p = __builtin_fma(p, t, sconst(0x1.2492492df148dp-3));
+  p = __builtin_fma(p, t, sconst(0x1.99999999952e2p-3));
+  p = __builtin_fma(p, t, sconst(0x1.5555555555558p-2));
+  const double hi = s + s;
+  const double ef = (double)k;
+  double r = __builtin_fma(ef, sconst(kLn2Lo), hi * t * p);
+  r = r + hi;
+  return __builtin_fma(ef, sconst(kLn2Hi), r);
+}
+
+// The log used by the bandwidth-bound logpdf bodies: one Newton step on the 24-bit v_rcp_f64 seed
+// (measured: 2.1e-15 relative after one step, tools/probe.hip), no residual correction.
+M355_HD double flog_stream(double x) { return flog_fast_t<1, false>(x); }
+
+// log(1 + w) for w >= 0 on the streaming path: log(u) + c/u with u = fl(1+w), c its rounding
+// error and 1/u ~ 2-u (exact to w^2, applied only where w < 1/2; beyond that c/u < 0.3 ulp of
+// the result).
+M355_HD double flog1p_stream(double w) {
+  const double u = 1.0 + w;
+  const double c = w - (u - 1.0);
+  const double corr = (w < 0.5) ? c * (2.0 - u) : 0.0;
+  return flog_stream(u) + corr;
+}
+
 // log(1 + w) with relative accuracy for small |w| (w >= -1; w < -1 -> NaN).
 M355_HD double flog1p(double w) {
   const double u = 1.0 + w;

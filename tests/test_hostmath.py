@@ -106,6 +106,21 @@ def test_host_log_log1p(hostlib):
         assert np.all(_close(got, exp, 1e-15) | (np.abs(got - exp) <= 6e-16 * np.abs(exp)))
 
 
+def test_host_streaming_logs(hostlib):
+    """flog_stream / flog1p_stream (one Newton step on a 24-bit reciprocal seed): <= 1e-14."""
+    rng = np.random.default_rng(5)
+    x = np.concatenate([np.exp(rng.uniform(-740, 700, 100000)), rng.uniform(0.5, 2, 100000),
+                        1 + rng.uniform(-1e-9, 1e-9, 1000), [1.0, 0.0, np.inf, -1.0, 5e-324, 1e-310, np.nan]])
+    with np.errstate(all="ignore"):
+        exp = np.log(x)
+        got = vec(hostlib, "hm_log_stream", x)
+        assert np.all(_close(got, exp, 1e-15) | (np.abs(got - exp) <= 1e-14 * np.abs(exp)))
+        w = np.concatenate([np.exp(rng.uniform(-60, 60, 100000)), rng.uniform(0, 1, 100000), [0.0, np.inf, np.nan]])
+        exp = np.log1p(w)
+        got = vec(hostlib, "hm_log1p_stream", w)
+        assert np.all(_close(got, exp, 1e-15) | (np.abs(got - exp) <= 1e-14 * np.abs(exp)))
+
+
 @pytest.mark.parametrize("arange", [(1e-3, 1), (1, 10), (10, 100), (100, 1e4)])
 def test_host_gammainc(hostlib, arange):
     rng = np.random.default_rng(1)

@@ -4,6 +4,7 @@
 // Build: hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off tools/stream_tune.hip -o tools/stream_tune
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -28,9 +29,23 @@ struct Copy {
   };
 };
 
+// D: -1 copy, 0..2 library bodies; 100+10*NR+CORR: gamma with flog_fast_t<NR,CORR>;
+// 200+10*NR+CORR: beta with flog_fast_t<NR,CORR>
 template <int D, class K> __device__ __forceinline__ double body(double x, const K& k) {
   if constexpr (D < 0) return x;
-  else return Dist<D>::template eval<M355_LOGPDF>(x, k);
+  else if constexpr (D >= 200) {
+    constexpr int NR = (D - 200) / 10;
+    constexpr bool CORR = (D % 10) != 0;
+    const double t = xlogy0_l(k.am1, flog_fast_t<NR, CORR>(x)) + xlogy0_l(k.bm1, flog_fast_t<NR, CORR>(1.0 - x));
+    const double r = t - k.lbeta;
+    return ((x < 0.0) | (x > 1.0)) ? -kInf : r;
+  } else if constexpr (D >= 100) {
+    constexpr int NR = (D - 100) / 10;
+    constexpr bool CORR = (D % 10) != 0;
+    const double t = xlogy0_l(k.am1, flog_fast_t<NR, CORR>(x));
+    const double r = (t - x * k.beta) + k.c;
+    return (x < 0.0) ? -kInf : r;
+  } else return Dist<D>::template eval<M355_LOGPDF>(x, k);
 }
 
 template <int D, int UNROLL, bool NT, int WPE, class K>
@@ -78,6 +93,31 @@ float run(const char* name, const double* x, double* out, long long n, const K& 
          blocks, ms, 16.0 * n / ms / 1e6, n / (ms * 1e-3));
   fflush(stdout);
   return ms;
+}
+
+// accuracy of the last launch's output against long double on the host (first 200k elements)
+template <class F> void accuracy(const char* name, const std::vector<double>& h, const double* out, F truth) {
+  const int m = 200000;
+  std::vector<double> o(m);
+  CHECK(hipMemcpy(o.data(), out, m * sizeof(double), hipMemcpyDeviceToHost));
+  double worst = 0;
+  for (int i = 0; i < m; ++i) {
+    const long double t = truth((long double)h[i]);
+    const double e = (double)(fabsl((long double)o[i] - t) / fmaxl(1.0L, fabsl(t)));
+    if (e > worst) worst = e;
+  }
+  printf("%-8s max |err|/max(1,|truth|) = %.3e\n", name, worst);
+}
+
+template <int D, class K> void quick(const char* name, const double* x, double* out, long long n, const K& k) {
+  run<D, 1, true, 1>(name, x, out, n, k, 0);
+  run<D, 2, true, 1>(name, x, out, n, k, 0);
+  run<D, 4, true, 1>(name, x, out, n, k, 0);
+  run<D, 4, false, 1>(name, x, out, n, k, 0);
+  run<D, 8, true, 1>(name, x, out, n, k, 0);
+  run<D, 4, true, 1>(name, x, out, n, k, 8192);
+  run<D, 4, true, 1>(name, x, out, n, k, 16384);
+  run<D, 2, true, 1>(name, x, out, n, k, 32768);
 }
 
 template <int D, class K> void sweep(const char* name, const double* x, double* out, long long n, const K& k) {
@@ -130,11 +170,38 @@ int main() {
     printf("hipMemcpyDtoD %.4f ms %.1f GB/s\n", ms / 10, 16.0 * n / (ms / 10) / 1e6);
   }
   Copy::K ck{0.0};
-  sweep<-1>("copy", x, out, n, ck);
   const double pn[3] = {0.3, 1.7, 0}, pg[3] = {2.5, 1.3, 0}, pb[3] = {2.0, 5.0, 0};
-  sweep<M355_NORMAL>("normal", x, out, n, Dist<M355_NORMAL>::derive(pn));
-  sweep<M355_GAMMA>("gamma", x, out, n, Dist<M355_GAMMA>::derive(pg));
-  sweep<M355_BETA>("beta", x, out, n, Dist<M355_BETA>::derive(pb));
+  const auto kn = Dist<M355_NORMAL>::derive(pn);
+  const auto kg = Dist<M355_GAMMA>::derive(pg);
+  const auto kb = Dist<M355_BETA>::derive(pb);
+  auto tg = [&](long double v) { return 1.5L * logl(v) - v * 1.3L + (long double)kg.c; };
+  auto tb = [&](long double v) { return logl(v) + 4.0L * logl(1.0L - v) - (long double)kb.lbeta; };
+  if (getenv("FULL_SWEEP")) {
+    sweep<-1>("copy", x, out, n, ck);
+    sweep<M355_NORMAL>("normal", x, out, n, kn);
+    sweep<M355_GAMMA>("gamma", x, out, n, kg);
+    sweep<M355_BETA>("beta", x, out, n, kb);
+  }
+  quick<-1>("copy", x, out, n, ck);
+  quick<M355_NORMAL>("normal", x, out, n, kn);
+  quick<M355_GAMMA>("gamma", x, out, n, kg);
+  accuracy("gamma", h, out, tg);
+  quick<110>("g_nr1", x, out, n, kg);
+  accuracy("g_nr1", h, out, tg);
+  quick<111>("g_nr1c", x, out, n, kg);
+  accuracy("g_nr1c", h, out, tg);
+  quick<120>("g_nr2", x, out, n, kg);
+  accuracy("g_nr2", h, out, tg);
+  quick<M355_BETA>("beta", x, out, n, kb);
+  accuracy("beta", h, out, tb);
+  quick<210>("b_nr1", x, out, n, kb);
+  accuracy("b_nr1", h, out, tb);
+  quick<211>("b_nr1c", x, out, n, kb);
+  accuracy("b_nr1c", h, out, tb);
+  quick<220>("b_nr2", x, out, n, kb);
+  accuracy("b_nr2", h, out, tb);
+  quick<221>("b_nr2c", x, out, n, kb);
+  accuracy("b_nr2c", h, out, tb);
   CHECK(hipDeviceSynchronize());
   return 0;
 }
