@@ -50,6 +50,24 @@ def make_inputs(torch, n, device, seed):
     return xs
 
 
+def pmc_traffic(dist_index):
+    """HBM bytes per launch of the elementwise kernel of CASES[dist_index], from the newest
+    profiles/rNN_hbm_traffic.json (written by tools/summarize_profile.py from separate
+    rocprofv3 --pmc passes of this same command); None if no profile has been committed."""
+    import glob
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic.json")))
+    if not files:
+        return None
+    with open(files[-1]) as f:
+        data = json.load(f)
+    key = f"k_scalar<{dist_index}, 0, false, true>"
+    for name, v in data.items():
+        if key in name:
+            return v["hbm_bytes_per_launch"]
+    return None
+
+
 def cpu_baseline(n_cpu, repeats):
     """The oracle's C leg (oracle/elemwise_c.c) on one host thread: same 6 evaluations per element
     (3 stored logpdf passes + 3 logpdf-and-sum passes) as one GPU step, on n_cpu elements."""
@@ -160,6 +178,7 @@ def main():
         value = 6.0 * n * world / (elapsed / args.steps)
         dom = max(range(len(CASES)), key=lambda j: kdur[j])  # slowest elementwise kernel
         achieved = 16.0 * n / (kdur[dom] * 1e-3) / 1e9
+        traffic = pmc_traffic(dom) if n == 100_000_000 else None
         line = {
             "metric": "logpdf evals/sec (Normal/Gamma/Beta, N=1e8 fp64 per GPU: elementwise + fused sum-logp)",
             "value": value,
@@ -187,7 +206,9 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": traffic,
+                "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, "
+                                  "profiles/*_hbm_traffic.json (reads = 2 x FETCH_SIZE on gfx950)" if traffic else None,
                 "algorithmic_bytes_per_launch": 16.0 * n,
                 "avg_launch_ms": kdur[dom],
             },

@@ -49,6 +49,7 @@ constexpr int kUnroll = 2;
 constexpr int kVec = 2;
 constexpr int kTile = kBlock * kVec * kUnroll;  // 1024 elements = 8 KiB of f64 in, 8 KiB out
 constexpr int kMaxBlocks = 32768;               // grid cap (tools/stream_tune.hip: best of the sweep)
+constexpr int kMaxReduceBlocks = 4096;         // sum-logp grid cap: keeps k_final's pass short
 constexpr int kMaxPeriodBytes = 64 * 1024;      // LDS table cap for k_periodic
 
 typedef double d2_t __attribute__((ext_vector_type(2)));
@@ -284,12 +285,13 @@ template <int D, int FN, bool REDUCE> int launch_fn(const LaunchArgs& a) {
   periodic_ok = periodic_ok && !all_scalar && P >= 1 && P < (unsigned long long)n &&
                 P * sizeof(typename DD::K) <= (size_t)kMaxPeriodBytes;
   const long long tiles = n / kTile;
+  const long long cap = REDUCE ? kMaxReduceBlocks : kMaxBlocks;
   int blocks;
   if (vec_ok && (all_scalar || periodic_ok)) {
-    blocks = (int)(tiles < 1 ? 1 : (tiles > kMaxBlocks ? kMaxBlocks : tiles));
+    blocks = (int)(tiles < 1 ? 1 : (tiles > cap ? cap : tiles));
   } else {
     const long long want = (n + kBlock - 1) / kBlock;
-    blocks = (int)(want < 1 ? 1 : (want > kMaxBlocks ? kMaxBlocks : want));
+    blocks = (int)(want < 1 ? 1 : (want > cap ? cap : want));
   }
   if (REDUCE && a.nblocks_out) *a.nblocks_out = blocks;
   if (vec_ok && all_scalar) {
