@@ -1,0 +1,139 @@
+#!/usr/bin/env python3
+"""Secondary measurements for BASELINE.json configs 2-4 (NOT the driver's headline line, which is
+bench.py): one JSON line per (config, function) with kernel-only time from HIP events on the launch
+stream.  Usage: python bench_configs.py [--config 2|3|4|all] [--n N] > profiles/rNN_configs.jsonl"""
+import argparse
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def timed(torch, fn, reps=5, warmup=1):
+    for _ in range(warmup):
+        fn()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(reps + 1)]
+    ev[0].record()
+    for i in range(reps):
+        fn()
+        ev[i + 1].record()
+    torch.cuda.synchronize()
+    ts = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(reps))
+    return ts[len(ts) // 2]
+
+
+def config2(torch, n):
+    """Gamma/Beta/StudentT(/Normal) logpdf+logcdf+logsf+ppf on n fp64 points, scalar params, plus
+    the period-1024 broadcast-parameter layout for logpdf."""
+    from distributions_amd import raw
+    from bench import make_inputs
+
+    dev = torch.device("cuda", 0)
+    xs = make_inputs(torch, n, dev, seed=2)
+    g = torch.Generator(device=dev).manual_seed(4)
+    z = torch.randn(n, dtype=torch.float64, device=dev, generator=g)
+    c = torch.zeros(n, dtype=torch.float64, device=dev)
+    for _ in range(5):
+        c += torch.randn(n, dtype=torch.float64, device=dev, generator=g) ** 2
+    xs["studentt"] = 2.0 * z / torch.sqrt(c / 5.0)
+    del z, c
+    q = torch.rand(n, dtype=torch.float64, device=dev, generator=g).clamp_(1e-12, 1 - 1e-12)
+    out = torch.empty(n, dtype=torch.float64, device=dev)
+    params = {"normal": (0.3, 1.7), "gamma": (2.5, 1.3), "beta": (2.0, 5.0), "studentt": (5.0, 0.0, 2.0)}
+    for name, p in params.items():
+        for fn in ("logpdf", "logcdf", "logsf", "ppf"):
+            src = q if fn == "ppf" else xs[name]
+            ms = timed(torch, lambda: raw.elemwise_into(name, fn, src, p, out), reps=3 if fn == "ppf" else 5)
+            print(json.dumps({"config": 2, "fn": f"{name}.{fn}", "n": n, "layout": "scalar params", "ms": ms,
+                              "evals_per_s": n / (ms * 1e-3), "GB_per_s_algorithmic": 16.0 * n / (ms * 1e-3) / 1e9}),
+                  flush=True)
+    # broadcast params: x viewed as (n/1024, 1024), params of shape (1024,) staged in LDS
+    from distributions_amd import gamma, normal
+
+    rows = n // 1024
+    xg = xs["gamma"][: rows * 1024].view(rows, 1024)
+    a_row = torch.linspace(0.5, 9.0, 1024, dtype=torch.float64, device=dev)
+    b_row = torch.linspace(0.3, 3.0, 1024, dtype=torch.float64, device=dev)
+    for label, f in (("gamma.logpdf", lambda: gamma.logpdf(xg, a_row, b_row)),
+                     ("normal.logpdf", lambda: normal.logpdf(xs["normal"][: rows * 1024].view(rows, 1024), a_row, b_row))):
+        ms = timed(torch, f, reps=5)
+        print(json.dumps({"config": 2, "fn": label, "n": rows * 1024, "layout": "params (1024,) row-periodic, LDS-staged "
+                          "(time includes torch.empty of the output)", "ms": ms, "evals_per_s": rows * 1024 / (ms * 1e-3),
+                          "GB_per_s_algorithmic": 16.0 * rows * 1024 / (ms * 1e-3) / 1e9}), flush=True)
+
+
+def config3(torch, n):
+    """rvs: n draws each, output-only streams (8 B/draw)."""
+    import ctypes
+
+    from distributions_amd import _lib
+    from distributions_amd._lib import DIST, F64, I64, Operand
+
+    L = _lib.lib()
+    dev = torch.device("cuda", 0)
+    outf = torch.empty(n, dtype=torch.float64, device=dev)
+    outi = torch.empty(n, dtype=torch.int64, device=dev)
+    cases = [("normal", (0.0, 1.0)), ("gamma", (2.5, 1.0)), ("gamma", (0.5, 1.0)), ("beta", (2.0, 5.0)),
+             ("studentt", (5.0, 0.0, 2.0)), ("poisson", (100.0,)), ("poisson", (4.0,)),
+             ("binomial", (1000.0, 0.3)), ("binomial", (10.0, 0.3))]
+    for name, p in cases:
+        ops = (Operand * len(p))()
+        for j, v in enumerate(p):
+            ops[j].ptr, ops[j].scalar, ops[j].div, ops[j].mod, ops[j].dtype = None, float(v), 1, 1, F64
+        disc = name in ("poisson", "binomial")
+        out = outi if disc else outf
+        stream = torch.cuda.current_stream(dev).cuda_stream
+
+        def go():
+            _lib.check(L.m355_rvs(DIST[name], I64 if disc else F64, n, len(p), ops, 20260313, DIST[name], 0,
+                                  out.data_ptr(), stream))
+
+        ms = timed(torch, go, reps=3)
+        print(json.dumps({"config": 3, "fn": f"{name}.rvs{p}", "n": n, "ms": ms, "draws_per_s": n / (ms * 1e-3),
+                          "GB_per_s_algorithmic": 8.0 * n / (ms * 1e-3) / 1e9}), flush=True)
+
+
+def config4(torch, n):
+    """MvNormal logpdf: n observations, d = 64, fp64 (variant A: one shared covariance)."""
+    import numpy as np
+
+    from distributions_amd import mvnormal
+
+    d = 64
+    rng = np.random.default_rng(6)
+    A = rng.normal(size=(d, d))
+    cov = A @ A.T / d + np.eye(d)
+    mu = np.random.default_rng(7).normal(size=d)
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev).manual_seed(8)
+    Lc = torch.linalg.cholesky(torch.from_numpy(cov).to(dev))
+    X = torch.from_numpy(mu).to(dev) + torch.randn(n, d, dtype=torch.float64, device=dev, generator=g) @ Lc.T
+    mu_t, cov_t = torch.from_numpy(mu).to(dev), torch.from_numpy(cov).to(dev)
+    ms = timed(torch, lambda: mvnormal.logpdf(X, mu_t, cov_t), reps=10, warmup=2)
+    nbytes = 8.0 * (n * d + n + d * d + d)
+    flops = n * (d * d + 3 * d) + d**3 / 3
+    print(json.dumps({"config": 4, "fn": "mvnormal.logpdf", "n": n, "d": d, "ms": ms, "obs_per_s": n / (ms * 1e-3),
+                      "GB_per_s_algorithmic": nbytes / (ms * 1e-3) / 1e9, "GFLOP_per_s": flops / (ms * 1e-3) / 1e9,
+                      "note": "whole call: Cholesky + solve + epilogue + output allocation"}), flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config", default="all")
+    ap.add_argument("--n", type=int, default=0)
+    args = ap.parse_args()
+    import torch
+
+    torch.cuda.set_device(0)
+    if args.config in ("2", "all"):
+        config2(torch, args.n or 100_000_000)
+    if args.config in ("3", "all"):
+        config3(torch, args.n or 1_000_000_000)
+    if args.config in ("4", "all"):
+        config4(torch, args.n or 100_000)
+
+
+if __name__ == "__main__":
+    main()

@@ -207,3 +207,59 @@ def sumlogp(dist: str, fn: str, x: Any, *params: Any):
     if _wants_torch(args):
         return out.reshape(())
     return float(out.item())
+
+
+# ------------------------------------------------------------------------------------------- rvs
+_STREAM_ID = {"normal": 0, "gamma": 1, "beta": 2, "studentt": 3, "poisson": 4, "binomial": 5}
+
+
+def _seed_of(random_state) -> Tuple[int, int]:
+    """(seed, counter offset) from the reference's `random_state` argument.  None: fresh OS entropy;
+    int: that seed; numpy Generator: a 63-bit seed drawn from it (which advances it, so repeated
+    calls differ, like the next_rng threading of pt.random); (seed, offset) tuple: explicit, for
+    sharded or resumed generation."""
+    if random_state is None:
+        return int.from_bytes(__import__("os").urandom(8), "little") >> 1, 0
+    if isinstance(random_state, tuple):
+        return int(random_state[0]), int(random_state[1])
+    if isinstance(random_state, (int, np.integer)):
+        return int(random_state), 0
+    if hasattr(random_state, "integers"):
+        return int(random_state.integers(0, 2**63 - 1)), 0
+    raise TypeError(f"random_state of type {type(random_state).__name__} is not supported")
+
+
+def rvs(dist: str, params: Sequence[Any], size=None, random_state=None, as_torch: bool = False):
+    """<dist>.rvs(*params, size=None, random_state=None): Philox4x32-10 counter-based draws on the
+    GPU (csrc/m355_rng.h).  size None -> broadcast shape of the parameters; int or tuple otherwise
+    (parameters must broadcast to it).  int64 for poisson/binomial, float64 otherwise."""
+    if len(params) != NPARAMS[dist]:
+        raise TypeError(f"{dist}.rvs takes {NPARAMS[dist]} parameters, got {len(params)}")
+    torch = _torch()
+    L = _lib.lib()
+    pshape = tuple(np.broadcast_shapes(*[_shape_of(a) for a in params]))
+    if size is None:
+        shape = pshape
+    else:
+        shape = (int(size),) if isinstance(size, (int, np.integer)) else tuple(int(s) for s in size)
+        if tuple(np.broadcast_shapes(shape, pshape)) != shape:
+            raise ValueError(f"parameters of shape {pshape} do not broadcast to size {shape}")
+    n = prod(shape)
+    seed, offset = _seed_of(random_state)
+    discrete = dist in ("poisson", "binomial")
+    device = _device_of(params, torch)
+    pl = Plan(shape, n, False, [OperandPlan("scalar")] + [classify(_shape_of(a), shape) for a in params])
+    with torch.cuda.device(device):
+        out = torch.empty(n, dtype=torch.int64 if discrete else torch.float64, device=device)
+        if n:
+            ops, keep = _build_operands(pl, (0.0, *params), torch, device)
+            stream = torch.cuda.current_stream(device).cuda_stream
+            rc = L.m355_rvs(DIST[dist], I64 if discrete else F64, n, len(params),
+                            ctypes.cast(ctypes.byref(ops, ctypes.sizeof(Operand)), ctypes.POINTER(Operand)),
+                            seed, _STREAM_ID[dist], offset, out.data_ptr(), stream)
+            _lib.check(rc)
+            del keep
+    out = out.reshape(shape)
+    if as_torch or _wants_torch(params):
+        return out
+    return out.cpu().numpy()

@@ -2,7 +2,9 @@
 elementwise kernels (csrc/m355_elemwise.h, bodies in csrc/m355_dists.h)."""
 
 from ._dispatch import elemwise as _elemwise
+from ._dispatch import rvs as _rvs
 from ._dispatch import sumlogp as _sumlogp
+
 
 def logpdf(x, n, p):
     """binomial.py:66-75 of the reference."""
@@ -37,3 +39,9 @@ def sf(x, n, p):
 def sum_logpdf(x, n, p):
     """sum(logpdf(x, n, p)) fused in one pass (the reference spells it pt.sum(logpdf(...)))."""
     return _sumlogp("binomial", "logpdf", x, n, p)
+
+
+def rvs(n, p, size=None, random_state=None):
+    """binomial.py:62-63 (int64) of the reference; Philox counter-based draws, KS / chi-square equivalent to
+    the reference sampler (not NumPy-stream-equal)."""
+    return _rvs("binomial", (n, p,), size=size, random_state=random_state)

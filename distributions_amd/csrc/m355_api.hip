@@ -102,6 +102,9 @@ int check_launch(int rc) {
 
 }  // namespace
 
+extern "C" int m355_rvs_impl(int dist, int out_dtype, long long n, const m355::GenericOps* ops, unsigned long long seed,
+                             unsigned stream_id, unsigned long long offset, void* out, hipStream_t s);
+
 extern "C" {
 
 int m355_version(void) { return M355_VERSION; }
@@ -160,6 +163,28 @@ int m355_sumlogp(int dist, int fn, int64_t n, const m355_operand* x, int nparams
   hipLaunchKernelGGL(k_final, dim3(1), dim3(m355::kBlock), 0, s, static_cast<const double*>(workspace), nblocks,
                      out_sum);
   return check_launch((int)hipGetLastError());
+}
+
+int m355_rvs(int dist, int out_dtype, int64_t n, int nparams, const m355_operand* params, uint64_t seed,
+             uint32_t stream_id, uint64_t counter_offset, void* out, void* stream) {
+  const int np = nparams_of(dist);
+  if (np < 0) return fail(M355_ERR_INVALID, "unknown distribution id %d", dist);
+  if (nparams != np) return fail(M355_ERR_INVALID, "distribution %d takes %d parameters, got %d", dist, np, nparams);
+  if (n < 0) return fail(M355_ERR_INVALID, "n must be >= 0");
+  if (params == nullptr) return fail(M355_ERR_INVALID, "params must not be NULL");
+  const bool discrete = dist == M355_POISSON || dist == M355_BINOMIAL;
+  if (out_dtype != M355_F64 && out_dtype != M355_F32 && !(discrete && out_dtype == M355_I64))
+    return fail(M355_ERR_INVALID, "out_dtype %d not valid for distribution %d", out_dtype, dist);
+  if (n == 0) return M355_OK;
+  if (out == nullptr) return fail(M355_ERR_INVALID, "out must not be NULL");
+  m355::GenericOps ops;
+  ops.x = m355::DevOperand{nullptr, 0.0, 1, 1, M355_F64};
+  for (int q = 0; q < 3; ++q) {
+    ops.p[q] = m355::DevOperand{nullptr, 0.0, 1, 1, M355_F64};
+    if (q < np && !convert(params[q], n, true, ops.p[q], "parameter")) return M355_ERR_INVALID;
+  }
+  return check_launch(m355_rvs_impl(dist, out_dtype, n, &ops, seed, stream_id, counter_offset, out,
+                                    static_cast<hipStream_t>(stream)));
 }
 
 }  // extern "C"

@@ -1,0 +1,303 @@
+// Counter-based sampling (the replacement for numpy.random.Generator behind pt.random.X:
+// normal.py:66-67, gamma.py:61-62, beta.py:86-87, studentt.py:96-97, poisson.py:66-67,
+// binomial.py:62-63).  Philox4x32-10 (Salmon et al., SC'11) keyed by the 64-bit seed; the counter
+// is (global element index lo, hi, attempt, stream id), so a draw is a pure function of
+// (seed, stream, element index, parameters): the concatenated output is identical for any
+// partition of the index range over GPUs, and any range can be regenerated (resume) from its
+// offset.  Samplers: Box-Muller normal, Marsaglia-Tsang gamma (alpha < 1 by the U^(1/alpha)
+// boost), beta as a gamma ratio, Student t as normal / sqrt(chi2/nu), Poisson by sequential
+// inversion (mu < 10) or PTRS (Hoermann 1993), binomial by sequential inversion (n*min(p,q) < 10)
+// or BTRS (Hoermann 1993).  Rejection loops run per lane with a bounded attempt count.
+#pragma once
+#include "m355_special.h"
+
+namespace m355 {
+
+struct Philox {
+  unsigned c[4];
+};
+
+M355_HD unsigned mulhi32(unsigned a, unsigned b) { return (unsigned)(((unsigned long long)a * b) >> 32); }
+
+// One Philox4x32-10 block.
+M355_HD Philox philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const unsigned hi0 = mulhi32(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+    const unsigned hi1 = mulhi32(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+    c0 = hi1 ^ c1 ^ k0;
+    c1 = lo1;
+    c2 = hi0 ^ c3 ^ k1;
+    c3 = lo0;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  Philox p;
+  p.c[0] = c0;
+  p.c[1] = c1;
+  p.c[2] = c2;
+  p.c[3] = c3;
+  return p;
+}
+
+// 53-bit uniform in the open interval (0, 1) from two 32-bit words.
+M355_HD double u53(unsigned hi, unsigned lo) {
+  const unsigned long long k = ((unsigned long long)(hi >> 5) << 26) | (unsigned long long)(lo >> 6);
+  return ((double)k + 0.5) * 0x1.0p-53;
+}
+
+// Stream of uniform pairs for one element: pair j is Philox block (index, attempt = j, stream).
+struct RngState {
+  unsigned idx_lo, idx_hi, stream, k0, k1;
+  unsigned attempt;
+};
+M355_HD void next_pair(RngState& s, double& u1, double& u2) {
+  const Philox p = philox4x32_10(s.idx_lo, s.idx_hi, s.attempt, s.stream, s.k0, s.k1);
+  s.attempt += 1;
+  u1 = u53(p.c[0], p.c[1]);
+  u2 = u53(p.c[2], p.c[3]);
+}
+
+// sqrt(a), a > 0 finite: hardware rsq seed (24 bits) + one coupled Newton step and a residual
+// correction (v_sqrt_f64 costs 17 FMAs, this ~8).
+M355_DEV double fsqrt(double a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  double y = __builtin_amdgcn_rsq(a);
+  double g = a * y;
+  double h = 0.5 * y;
+  double r = __builtin_fma(-h, g, 0.5);
+  g = __builtin_fma(g, r, g);
+  h = __builtin_fma(h, r, h);
+  const double d = __builtin_fma(-g, g, a);
+  return __builtin_fma(d, h, g);
+#else
+  return ::sqrt(a);
+#endif
+}
+
+M355_DEV void sincos_2pi(double u, double& s, double& c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  ::sincospi(2.0 * u, &s, &c);
+#else
+  s = ::sin(2.0 * kPi * u);
+  c = ::cos(2.0 * kPi * u);
+#endif
+}
+
+// Two independent standard normals from one uniform pair (Box-Muller).
+M355_DEV void normal_pair(double u1, double u2, double& z0, double& z1) {
+  const double r = fsqrt(-2.0 * flog_stream(u1));
+  double s, c;
+  sincos_2pi(u2, s, c);
+  z0 = r * c;
+  z1 = r * s;
+}
+
+constexpr int kMaxAttempts = 256;  // P(no acceptance) < 1e-50 for every sampler below
+
+// Gamma(shape a, scale 1), Marsaglia & Tsang (2000).  a == 0 -> 0; a < 0 or NaN -> NaN.
+M355_DEV double sample_std_gamma(RngState& st, double a) {
+  if (!(a >= 0.0)) return kNaN;
+  if (a == 0.0) return 0.0;
+  if (a == kInf) return kInf;
+  const bool boost = a < 1.0;
+  const double aa = boost ? a + 1.0 : a;
+  const double d = aa - 1.0 / 3.0;
+  const double c = 1.0 / (3.0 * fsqrt(d));
+  double v = 1.0;
+  for (int it = 0; it < kMaxAttempts; ++it) {
+    double u1, u2, u3, u4;
+    next_pair(st, u1, u2);
+    next_pair(st, u3, u4);
+    double x0, x1;
+    normal_pair(u1, u2, x0, x1);
+    // two candidates per normal pair
+    bool ok = false;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const double x = j == 0 ? x0 : x1;
+      const double u = j == 0 ? u3 : u4;
+      const double t = 1.0 + c * x;
+      if (ok || !(t > 0.0)) continue;
+      const double vv = t * t * t;
+      const double x2 = x * x;
+      if (u < 1.0 - 0.0331 * x2 * x2 || flog_stream(u) < 0.5 * x2 + d * (1.0 - vv + flog_stream(vv))) {
+        v = vv;
+        ok = true;
+      }
+    }
+    if (ok) break;
+  }
+  double g = d * v;
+  if (boost) {
+    double u1, u2;
+    next_pair(st, u1, u2);
+    g *= exp_(flog_stream(u1) / a);
+  }
+  return g;
+}
+
+// log(k!) for integer-valued k >= 0: table below 16, Stirling's series above.
+M355_DEV double lfactorial(double k) {
+  if (k < 16.0) {
+    const double t[16] = {0.0,
+                          0.0,
+                          0.69314718055994530942,
+                          1.79175946922805500081,
+                          3.17805383034794561965,
+                          4.78749174278204599425,
+                          6.57925121201010099506,
+                          8.52516136106541430017,
+                          10.60460290274525022842,
+                          12.80182748008146961121,
+                          15.10441257307551529523,
+                          17.50230784587388583929,
+                          19.98721449566188614952,
+                          22.55216385312342288557,
+                          25.19122118273868150009,
+                          27.89927138384089156609};
+    return t[(int)k];
+  }
+  const double z = k + 1.0;
+  return (z - 0.5) * flog_stream(z) - z + kLogSqrt2Pi + stirling_corr(z);
+}
+
+// Poisson(mu) as a double holding an integer.  mu == 0 -> 0; mu < 0 or NaN -> NaN.
+M355_DEV double sample_poisson(RngState& st, double mu) {
+  if (!(mu >= 0.0)) return kNaN;
+  if (mu == 0.0) return 0.0;
+  if (mu < 10.0) {
+    // sequential inversion from one uniform
+    double u1, u2;
+    next_pair(st, u1, u2);
+    double p = exp_(-mu), s = p, k = 0.0;
+    while (u1 > s && k < 200.0) {
+      k += 1.0;
+      p *= mu / k;
+      s += p;
+    }
+    return k;
+  }
+  // PTRS (Hoermann 1993, "The transformed rejection method for generating Poisson random variables")
+  const double slam = fsqrt(mu), loglam = flog_stream(mu);
+  const double b = 0.931 + 2.53 * slam;
+  const double a = -0.059 + 0.02483 * b;
+  const double invalpha = 1.1239 + 1.1328 / (b - 3.4);
+  const double vr = 0.9277 - 3.6224 / (b - 2.0);
+  double k = floor_(mu);
+  for (int it = 0; it < kMaxAttempts; ++it) {
+    double u1, v;
+    next_pair(st, u1, v);
+    const double u = u1 - 0.5;
+    const double us = 0.5 - __builtin_fabs(u);
+    k = floor_((2.0 * a / us + b) * u + mu + 0.43);
+    if (us >= 0.07 && v <= vr) break;
+    if (k < 0.0 || (us < 0.013 && v > us)) continue;
+    if (flog_stream(v) + flog_stream(invalpha) - flog_stream(a / (us * us) + b) <= -mu + k * loglam - lfactorial(k)) break;
+  }
+  return k;
+}
+
+// Stirling tail log(k!) - [ (k+1/2) log(k+1) - (k+1) + log(2 pi)/2 ] used by BTRS.
+M355_DEV double stirling_tail(double k) {
+  if (k < 10.0) {
+    const double t[10] = {0.0810614667953272,  0.0413406959554092,  0.0276779256849983,  0.02079067210376509,
+                          0.0166446911898211,  0.0138761288230707,  0.0118967099458917,  0.0104112652619720,
+                          0.00925546218271273, 0.00833056343336287};
+    return t[(int)k];
+  }
+  const double kp1 = k + 1.0, kp1sq = kp1 * kp1;
+  return (1.0 / 12.0 - (1.0 / 360.0 - 1.0 / 1260.0 / kp1sq) / kp1sq) / kp1;
+}
+
+// Binomial(n, p) as a double holding an integer.  n must be a non-negative integer value.
+M355_DEV double sample_binomial(RngState& st, double n, double p) {
+  if (!(n >= 0.0) || !(p >= 0.0) || !(p <= 1.0)) return kNaN;
+  if (n == 0.0 || p == 0.0) return 0.0;
+  if (p == 1.0) return n;
+  const bool flip = p > 0.5;
+  const double pp = flip ? 1.0 - p : p;
+  const double q = 1.0 - pp;
+  double k = 0.0;
+  if (n * pp < 10.0) {
+    // sequential inversion from one uniform (restarts in the ~1e-16 tail the sum cannot reach)
+    const double r = pp / q;
+    for (int it = 0; it < kMaxAttempts; ++it) {
+      double u1, u2;
+      next_pair(st, u1, u2);
+      double px = exp_(n * flog1p(-pp)), s = px;
+      k = 0.0;
+      while (u1 > s && k < n) {
+        k += 1.0;
+        px *= r * (n - k + 1.0) / k;
+        s += px;
+      }
+      if (u1 <= s || k >= n) break;
+    }
+  } else {
+    // BTRS (Hoermann 1993, "The generation of binomial random variates")
+    const double spq = fsqrt(n * pp * q);
+    const double b = 1.15 + 2.53 * spq;
+    const double a = -0.0873 + 0.0248 * b + 0.01 * pp;
+    const double c = n * pp + 0.5;
+    const double vr = 0.92 - 4.2 / b;
+    const double r = pp / q;
+    const double alpha = (2.83 + 5.1 / b) * spq;
+    const double m = floor_((n + 1.0) * pp);
+    k = m;
+    for (int it = 0; it < kMaxAttempts; ++it) {
+      double u1, v;
+      next_pair(st, u1, v);
+      const double u = u1 - 0.5;
+      const double us = 0.5 - __builtin_fabs(u);
+      k = floor_((2.0 * a / us + b) * u + c);
+      if (us >= 0.07 && v <= vr) break;
+      if (k < 0.0 || k > n) continue;
+      const double lv = flog_stream(v * alpha / (a / (us * us) + b));
+      const double upper = (m + 0.5) * flog_stream((m + 1.0) / (r * (n - m + 1.0))) +
+                           (n + 1.0) * flog_stream((n - m + 1.0) / (n - k + 1.0)) +
+                           (k + 0.5) * flog_stream(r * (n - k + 1.0) / (k + 1.0)) + stirling_tail(m) +
+                           stirling_tail(n - m) - stirling_tail(k) - stirling_tail(n - k);
+      if (lv <= upper) break;
+    }
+  }
+  return flip ? n - k : k;
+}
+
+// One draw of distribution D for global element index `idx` (parameters already fetched).
+template <int D> M355_DEV double sample_one(unsigned long long idx, unsigned long long seed, unsigned stream,
+                                           const double* p) {
+  RngState st;
+  // Normal draws come in Box-Muller pairs: elements 2k and 2k+1 share block k (cos / sin branch).
+  const unsigned long long cidx = (D == M355_NORMAL) ? (idx >> 1) : idx;
+  st.idx_lo = (unsigned)cidx;
+  st.idx_hi = (unsigned)(cidx >> 32);
+  st.stream = stream;
+  st.k0 = (unsigned)seed;
+  st.k1 = (unsigned)(seed >> 32);
+  st.attempt = 0;
+  if constexpr (D == M355_NORMAL) {  // normal.py:66-67: mu + sigma * z
+    double u1, u2, z0, z1;
+    next_pair(st, u1, u2);
+    normal_pair(u1, u2, z0, z1);
+    return p[0] + p[1] * ((idx & 1ull) ? z1 : z0);
+  } else if constexpr (D == M355_GAMMA) {  // gamma.py:61-62: shape alpha, scale 1/beta
+    return sample_std_gamma(st, p[0]) / p[1];
+  } else if constexpr (D == M355_BETA) {  // beta.py:86-87
+    const double ga = sample_std_gamma(st, p[0]);
+    const double gb = sample_std_gamma(st, p[1]);
+    return ga / (ga + gb);
+  } else if constexpr (D == M355_STUDENTT) {  // studentt.py:96-97: mu + sigma * z / sqrt(chi2_nu / nu)
+    double u1, u2, z0, z1;
+    next_pair(st, u1, u2);
+    normal_pair(u1, u2, z0, z1);
+    const double g = sample_std_gamma(st, 0.5 * p[0]);  // chi2_nu / 2
+    return p[1] + p[2] * z0 * fsqrt(0.5 * p[0] / g);
+  } else if constexpr (D == M355_POISSON) {  // poisson.py:66-67
+    return sample_poisson(st, p[0]);
+  } else {  // binomial.py:62-63
+    return sample_binomial(st, p[0], p[1]);
+  }
+}
+
+}  // namespace m355

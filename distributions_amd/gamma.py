@@ -2,7 +2,9 @@
 elementwise kernels (csrc/m355_elemwise.h, bodies in csrc/m355_dists.h)."""
 
 from ._dispatch import elemwise as _elemwise
+from ._dispatch import rvs as _rvs
 from ._dispatch import sumlogp as _sumlogp
+
 
 def logpdf(x, alpha, beta):
     """gamma.py:77-82 of the reference."""
@@ -47,3 +49,9 @@ def isf(q, alpha, beta):
 def sum_logpdf(x, alpha, beta):
     """sum(logpdf(x, alpha, beta)) fused in one pass (the reference spells it pt.sum(logpdf(...)))."""
     return _sumlogp("gamma", "logpdf", x, alpha, beta)
+
+
+def rvs(alpha, beta, size=None, random_state=None):
+    """gamma.py:61-62 (shape alpha, scale 1/beta) of the reference; Philox counter-based draws, KS / chi-square equivalent to
+    the reference sampler (not NumPy-stream-equal)."""
+    return _rvs("gamma", (alpha, beta,), size=size, random_state=random_state)

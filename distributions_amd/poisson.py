@@ -2,7 +2,9 @@
 elementwise kernels (csrc/m355_elemwise.h, bodies in csrc/m355_dists.h)."""
 
 from ._dispatch import elemwise as _elemwise
+from ._dispatch import rvs as _rvs
 from ._dispatch import sumlogp as _sumlogp
+
 
 def logpdf(x, mu):
     """poisson.py:70-71 of the reference."""
@@ -37,3 +39,9 @@ def sf(x, mu):
 def sum_logpdf(x, mu):
     """sum(logpdf(x, mu)) fused in one pass (the reference spells it pt.sum(logpdf(...)))."""
     return _sumlogp("poisson", "logpdf", x, mu)
+
+
+def rvs(mu, size=None, random_state=None):
+    """poisson.py:66-67 (int64) of the reference; Philox counter-based draws, KS / chi-square equivalent to
+    the reference sampler (not NumPy-stream-equal)."""
+    return _rvs("poisson", (mu,), size=size, random_state=random_state)

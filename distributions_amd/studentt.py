@@ -2,7 +2,9 @@
 elementwise kernels (csrc/m355_elemwise.h, bodies in csrc/m355_dists.h)."""
 
 from ._dispatch import elemwise as _elemwise
+from ._dispatch import rvs as _rvs
 from ._dispatch import sumlogp as _sumlogp
+
 
 def logpdf(x, nu, mu, sigma):
     """studentt.py:108-119 of the reference."""
@@ -47,3 +49,9 @@ def isf(q, nu, mu, sigma):
 def sum_logpdf(x, nu, mu, sigma):
     """sum(logpdf(x, nu, mu, sigma)) fused in one pass (the reference spells it pt.sum(logpdf(...)))."""
     return _sumlogp("studentt", "logpdf", x, nu, mu, sigma)
+
+
+def rvs(nu, mu, sigma, size=None, random_state=None):
+    """studentt.py:96-97 of the reference; Philox counter-based draws, KS / chi-square equivalent to
+    the reference sampler (not NumPy-stream-equal)."""
+    return _rvs("studentt", (nu, mu, sigma,), size=size, random_state=random_state)

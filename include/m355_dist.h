@@ -106,6 +106,20 @@ int m355_sumlogp(int dist, int fn, int64_t n, const m355_operand* x, int nparams
                  const m355_operand* params, double* out_sum, void* workspace,
                  size_t workspace_bytes, void* stream);
 
+/*
+ * out[i] = one draw of `dist` with the parameters of element i, i in [0, n): replaces
+ * pt.random.{normal,gamma,beta,t,poisson,binomial}(..., rng, size) -> numpy.random.Generator
+ * (normal.py:66-67, gamma.py:61-62 [shape alpha, scale 1/beta], beta.py:86-87, studentt.py:96-97,
+ * poisson.py:66-67, binomial.py:62-63).  Philox4x32-10, key = seed, counter = (counter_offset + i,
+ * attempt, stream_id): the draw of global element counter_offset + i does not depend on how the
+ * range is split over calls or GPUs.  out_dtype: M355_F64 / M355_F32, or M355_I64 for the discrete
+ * distributions (the reference returns int64).  Parameters as in m355_elemwise (float64 arrays
+ * or scalars, indexed by (i / div) % mod).  Statistically equivalent to the reference sampler
+ * (KS / chi-square), not stream-equal to NumPy's PCG64.
+ */
+int m355_rvs(int dist, int out_dtype, int64_t n, int nparams, const m355_operand* params, uint64_t seed,
+             uint32_t stream_id, uint64_t counter_offset, void* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

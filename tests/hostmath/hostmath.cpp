@@ -61,3 +61,25 @@ extern "C" void hm_betaincinv(long n, const double* a, const double* b, const do
 extern "C" void hm_lbeta(long n, const double* a, const double* b, double* out) { for (long i = 0; i < n; ++i) out[i] = lbeta_(a[i], b[i]); }
 extern "C" void hm_log_stream(long n, const double* x, double* out) { for (long i = 0; i < n; ++i) out[i] = flog_stream(x[i]); }
 extern "C" void hm_log1p_stream(long n, const double* x, double* out) { for (long i = 0; i < n; ++i) out[i] = flog1p_stream(x[i]); }
+
+#include "../../distributions_amd/csrc/m355_rng.h"
+extern "C" void hm_philox(const unsigned* ctr, const unsigned* key, unsigned* out) {
+  const Philox p = philox4x32_10(ctr[0], ctr[1], ctr[2], ctr[3], key[0], key[1]);
+  for (int i = 0; i < 4; ++i) out[i] = p.c[i];
+}
+template <int D> static void rvs_loop(long n, const double* p, unsigned long long seed, unsigned stream,
+                                      unsigned long long offset, double* out) {
+  for (long i = 0; i < n; ++i) out[i] = sample_one<D>(offset + (unsigned long long)i, seed, stream, p);
+}
+extern "C" int hm_rvs(int dist, long n, const double* p, unsigned long long seed, unsigned stream,
+                      unsigned long long offset, double* out) {
+  switch (dist) {
+    case M355_NORMAL: rvs_loop<M355_NORMAL>(n, p, seed, stream, offset, out); return 0;
+    case M355_GAMMA: rvs_loop<M355_GAMMA>(n, p, seed, stream, offset, out); return 0;
+    case M355_BETA: rvs_loop<M355_BETA>(n, p, seed, stream, offset, out); return 0;
+    case M355_STUDENTT: rvs_loop<M355_STUDENTT>(n, p, seed, stream, offset, out); return 0;
+    case M355_POISSON: rvs_loop<M355_POISSON>(n, p, seed, stream, offset, out); return 0;
+    case M355_BINOMIAL: rvs_loop<M355_BINOMIAL>(n, p, seed, stream, offset, out); return 0;
+  }
+  return -1;
+}

@@ -27,7 +27,7 @@ _dp = ctypes.POINTER(ctypes.c_double)
 @pytest.fixture(scope="session")
 def hostlib():
     csrc = os.path.join(HERE, "..", "distributions_amd", "csrc")
-    deps = [SRC] + [os.path.join(csrc, f) for f in ("m355_math.h", "m355_special.h", "m355_dists.h")]
+    deps = [SRC] + [os.path.join(csrc, f) for f in ("m355_math.h", "m355_special.h", "m355_dists.h", "m355_rng.h")]
     if not os.path.exists(LIB) or any(os.path.getmtime(d) > os.path.getmtime(LIB) for d in deps):
         subprocess.check_call(["g++", "-O2", "-mfma", "-std=c++17", "-shared", "-fPIC", "-o", LIB, SRC])
     return ctypes.CDLL(LIB)
