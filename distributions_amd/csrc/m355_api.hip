@@ -5,11 +5,13 @@
 #include <cstdio>
 
 #include "m355_elemwise.h"
+#include "m355_error.h"
 
 namespace {
-
 thread_local char g_err[512] = "";
+}
 
+namespace m355 {
 int fail(int code, const char* fmt, ...) {
   va_list ap;
   va_start(ap, fmt);
@@ -17,6 +19,10 @@ int fail(int code, const char* fmt, ...) {
   va_end(ap);
   return code;
 }
+}  // namespace m355
+
+namespace {
+using m355::fail;
 
 // Fixed-order sum of the per-workgroup partials (one workgroup): deterministic total.
 __global__ __launch_bounds__(m355::kBlock) void k_final(const double* __restrict__ partials, int nparts,

@@ -377,7 +377,8 @@ M355_DEV_HEAVY double betainc_xy(double a, double b, double x, double y, double 
   if (!(a > 0.0) || !(b > 0.0) || !(x >= 0.0) || !(x <= 1.0)) return kNaN;
   if (x == 0.0) return 0.0;
   if (y == 0.0) return 1.0;  // (x may have rounded to 1 while y is still a tiny positive number)
-  if (b * x <= 1.0 && x <= 0.95) return betainc_pseries(a, b, x, lbeta);
+  // Evaluate on the side where x is below the mean-like threshold (a+1)/(a+b+2), where both
+  // expansions converge fast; the power series only while x^n dies quickly (x <= 0.35).
   bool flip = false;
   if (x > fdiv(a + 1.0, a + b + 2.0)) {
     flip = true;
@@ -385,13 +386,18 @@ M355_DEV_HEAVY double betainc_xy(double a, double b, double x, double y, double 
     t = x; x = y; y = t;
   }
   double r;
-  if (flip && b * x <= 1.0 && x <= 0.95) {
+  if (b * x <= 1.0 && x <= 0.35) {
     r = betainc_pseries(a, b, x, lbeta);
   } else {
     const double lk = log_beta_kernel(a, b, x, y, lbeta);
     r = (lk < kMinLog) ? 0.0 : fdiv(exp_(lk) * betainc_cf(a, b, x), a);
   }
-  if (flip) r = (r <= kEps) ? 1.0 - kEps : 1.0 - r;
+  if (flip) {
+    // 1 - r cancels when the answer is small; where the (slow but direct) power series of the
+    // unflipped problem applies, use it instead.  After the swap that problem is I_y(b, a).
+    if (r > 0.9 && a * y <= 1.0 && y <= 0.95) return betainc_pseries(b, a, y, lbeta);
+    r = (r <= kEps) ? 1.0 - kEps : 1.0 - r;
+  }
   return r;
 }
 M355_DEV double betainc_(double a, double b, double x, double lbeta) {

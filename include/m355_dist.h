@@ -120,6 +120,33 @@ int m355_sumlogp(int dist, int fn, int64_t n, const m355_operand* x, int nparams
 int m355_rvs(int dist, int out_dtype, int64_t n, int nparams, const m355_operand* params, uint64_t seed,
              uint32_t stream_id, uint64_t counter_offset, void* out, void* stream);
 
+/*
+ * Multivariate normal / Student t log-density: out[r] = logpdf(x[r, :]) for r in [0, n), x row-major
+ * n x d (d <= 128).  Replaces mvnormal.logpdf (mvnormal.py:80-83 with quaddist_chol :17-37 and
+ * _logdet_from_cholesky :9-14) for kind 0 and mvstudentt.logpdf (mvstudentt.py:58-68) for kind 1:
+ * Cholesky of every covariance (one workgroup each, in LDS), one forward substitution per
+ * observation row, sum of squares and the epilogue fused.  mu: d doubles shared by all rows
+ * (mu_stride 0) or one row per observation (mu_stride d).  cov: ncov matrices d x d; observation
+ * r uses matrix (r / cov_div) % cov_mod (shared covariance: ncov = 1).  A covariance that is not
+ * positive definite yields NaN, as the reference does (posdef is ignored, mvnormal.py:81).
+ * workspace: m355_mvn_workspace_bytes(d, ncov) bytes of device memory (the factors).
+ */
+size_t m355_mvn_workspace_bytes(int d, int64_t ncov);
+int m355_mvn_logpdf(int kind, int64_t n, int d, const double* x, const double* mu, int64_t mu_stride,
+                    const double* cov, int64_t ncov, int64_t cov_div, int64_t cov_mod, double nu,
+                    double* out, void* workspace, size_t workspace_bytes, void* stream);
+
+/*
+ * Matrix normal log-density (matrixnormal.py:68-94): X is nbatch x m x n row-major, mu m x n
+ * (mu_batched 0) or nbatch x m x n, rowcov nrow x m x m and colcov ncol x n x n with nrow, ncol in
+ * {1, nbatch}; out has nbatch entries:  -0.5 * || L_V^-1 (L_U^-1 (X - M))^T ||_F^2 - log_norm.
+ */
+size_t m355_matrixnormal_workspace_bytes(int64_t nbatch, int m, int n, int64_t nrow, int64_t ncol);
+int m355_matrixnormal_logpdf(int64_t nbatch, int m, int n, const double* X, const double* mu,
+                             int mu_batched, const double* rowcov, int64_t nrow, const double* colcov,
+                             int64_t ncol, double* out, void* workspace, size_t workspace_bytes,
+                             void* stream);
+
 #ifdef __cplusplus
 }
 #endif
