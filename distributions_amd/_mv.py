@@ -35,7 +35,8 @@ def _bind():
 def _t(a, torch, device):
     if _is_torch(a):
         return a.to(device=device, dtype=torch.float64)
-    return torch.from_numpy(np.ascontiguousarray(np.asarray(a, dtype=np.float64))).to(device)
+    a = np.asarray(a, dtype=np.float64)  # np.ascontiguousarray would promote 0-d to 1-d
+    return torch.from_numpy(np.array(a, order="C", copy=True)).to(device)
 
 
 def mv_logpdf(kind: int, x, mu, cov, nu: float = 0.0):
