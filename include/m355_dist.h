@@ -147,6 +147,40 @@ int m355_matrixnormal_logpdf(int64_t nbatch, int m, int n, const double* X, cons
                              int64_t ncol, double* out, void* workspace, size_t workspace_bytes,
                              void* stream);
 
+/*
+ * Categorical (categorical.py:60-112): out[i] = fn(x[i]; p) for one probability vector p of k
+ * entries (normalised on the device as p / sum(p), categorical.py:7-9).  fn is an m355_fn:
+ * LOGPDF/PDF (:64-74, :60-61: valid iff 0 <= x < k and x == floor(x), gather log p at the clipped
+ * integer, else -inf), CDF/LOGCDF/SF/LOGSF (:77-97: gather of the sequential cumsum at
+ * clip(floor(x), 0, k-1) through cdf_bounds(., x, 0, k-1)), PPF/ISF (:100-112: smallest index whose
+ * cumsum >= q, through ppf_bounds_disc(., q, 0, k-1)).  x may be float64 / float32 / int64 (int64
+ * observations are compared as integers); out is float64.  A NaN observation gives -inf (logpdf)
+ * or NaN (cdf family, where the reference's index is undefined).
+ * workspace: m355_categorical_workspace_bytes(k) bytes of device memory (the three tables).
+ */
+size_t m355_categorical_workspace_bytes(int k);
+int m355_categorical(int fn, int64_t n, const void* x, int x_dtype, const double* p, int k, double* out,
+                     void* workspace, size_t workspace_bytes, void* stream);
+/* Categorical draws (categorical.py:115-117 -> pt.random.categorical): inverse CDF of one Philox
+ * uniform per element, counter = counter_offset + i; int64 out. */
+int m355_categorical_rvs(int64_t n, const double* p, int k, uint64_t seed, uint32_t stream_id,
+                         uint64_t counter_offset, int64_t* out, void* workspace, size_t workspace_bytes,
+                         void* stream);
+
+/*
+ * Multinomial log-pmf (multinomial.py:39-54): x is rows x k row-major (float64 / float32 / int64),
+ * out[r] = gammaln(n+1) - sum_j gammaln(x[r,j]+1) + sum_j x[r,j] * log(max(p[j], 1e-10)), or -inf
+ * when any x[r,j] < 0 or sum_j x[r,j] != n (both decided exactly: integer-valued counts sum exactly
+ * in float64 below 2^53).  n: scalar (n_ptr NULL) or array indexed by r % n_mod; p: one row of k
+ * (p_rows 1) or rows x k.
+ */
+int m355_multinomial_logpdf(int64_t rows, int k, const void* x, int x_dtype, const double* n_ptr, double n_scalar,
+                            int64_t n_mod, const double* p, int64_t p_rows, double* out, void* stream);
+/* Multinomial draws (multinomial.py:57-58 -> pt.random.multinomial): conditional binomials per
+ * row, rows x k int64 out; row r uses Philox counter counter_offset + r. */
+int m355_multinomial_rvs(int64_t rows, int k, double n, const double* p, uint64_t seed, uint32_t stream_id,
+                         uint64_t counter_offset, int64_t* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

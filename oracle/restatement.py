@@ -551,6 +551,33 @@ def categorical_ppf(q, p):
         return ppf_bounds_disc(np.min(masked, axis=-1), q, 0, k - 1)
 
 
+def categorical_pdf(x, p):
+    """categorical.py:60-61."""
+    return np.exp(categorical_logpdf(x, p))
+
+
+def categorical_logcdf(x, p):
+    """categorical.py:88-89."""
+    with _quiet():
+        return np.log(categorical_cdf(x, p))
+
+
+def categorical_sf(x, p):
+    """categorical.py:92-93."""
+    return 1.0 - categorical_cdf(x, p)
+
+
+def categorical_logsf(x, p):
+    """categorical.py:96-97."""
+    with _quiet():
+        return np.log1p(-categorical_cdf(x, p))
+
+
+def categorical_isf(q, p):
+    """categorical.py:111-112."""
+    return categorical_ppf(1.0 - np.asarray(q, dtype=_F), p)
+
+
 # --------------------------------------------------------------------------- multinomial
 def multinomial_logpdf(x, n, p):
     """multinomial.py:39-54."""
