@@ -1,20 +1,34 @@
 // Multivariate log-densities: batched Cholesky + triangular solve + fused epilogue
 // (mvnormal.py:9-37,80-83; mvstudentt.py:58-68; matrixnormal.py:68-94 of the reference).
 //
-//   k_cholesky   one workgroup per covariance matrix, the matrix in LDS (d <= 128): right-looking
-//                factorisation, writes L (lower, row-major, upper part zeroed), 1/diag(L) and
-//                logdet = 2*sum(log diag) (mvnormal.py:9-14).  A non-positive pivot gives NaN, as
-//                the reference's Cholesky does (posdef is ignored there, quirk Q5).
-//   k_solve      one thread per observation: forward substitution L y = x - mu in the order of the
-//                reference's per-row solve (mvnormal.py:30-31), y kept in LDS column-major
-//                ([component][thread]: conflict-free), L read through wave-uniform (scalar) loads
-//                when the covariance is shared; quad = sum y^2 (mvnormal.py:32) and the logpdf
-//                epilogue fused.  Generic strides make the same kernel serve both solves of
-//                matrixnormal (columns of X-M against L_U, then rows against L_V).
+//   k_cholesky     one workgroup (one or two wavefronts, lane = matrix row) per covariance matrix,
+//                  the matrix in LDS with an odd row stride (conflict-free row walks): left-looking
+//                  column factorisation -- row i accumulates a[i][j] - sum_{k<j} L[i][k] L[j][k] in
+//                  registers (4 independent chains), so a column costs two barriers and no LDS
+//                  writes in its inner loop.  Writes L (lower, row-major, upper part zeroed),
+//                  1/diag(L) and logdet = 2*sum(log diag) (mvnormal.py:9-14).  A non-positive pivot
+//                  gives NaN, as the reference's Cholesky does (posdef is ignored there, quirk Q5).
+//                  For a shared covariance it also emits the MFMA operand fragments k_solve_mfma
+//                  consumes: -L in 16x16 blocks and the inverses of the diagonal blocks.
+//   k_solve_mfma   shared covariance, contiguous observations: blocked forward substitution on
+//                  v_mfma_f64_16x16x4_f64.  A wavefront owns tiles of 16 observations (the N
+//                  dimension); per 16-row block I of L:  R_I = Delta_I - sum_{J<I} L_IJ Y_J  and
+//                  Y_I = inv(L_II) R_I, each 16x16x16 product = 4 MFMAs.  The D layout of the f64
+//                  MFMA (row = (lane>>4) + 4*reg) is exactly its B-operand layout for k-step `reg`,
+//                  so Y_J feeds the next products straight from registers.  Observation tiles are
+//                  contiguous in HBM: coalesced 16-byte loads (next tile prefetched into registers
+//                  while the current one is in the MFMA chain), staged through a wave-private LDS
+//                  region to reach the MFMA layout.  quad = sum y^2 (mvnormal.py:32) and the logpdf
+//                  epilogue are fused.
+//   k_solve        one thread per observation: forward substitution L y = x - mu in the order of the
+//                  reference's per-row solve (mvnormal.py:30-31), y kept in LDS column-major
+//                  ([component][thread]: conflict-free).  Serves batched covariances and the
+//                  strided solves of matrixnormal (columns of X-M against L_U, then rows against L_V).
 #include <hip/hip_runtime.h>
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 
 #include "m355_error.h"
 #include "m355_special.h"
@@ -25,40 +39,201 @@ namespace m355 {
 constexpr int kMaxDim = 128;
 constexpr int kSolveThreads = 64;
 
+typedef double d2_t __attribute__((ext_vector_type(2)));
+typedef double d4_t __attribute__((ext_vector_type(4)));
+
 // workspace layout per matrix: L (d*d) | invdiag (d) | logdet (1)
 __host__ __device__ inline size_t chol_stride(int d) { return (size_t)d * d + d + 1; }
+__host__ __device__ inline int nblk16(int d) { return (d + 15) / 16; }
+// MFMA operand fragments of one factor: NB(NB+1)/2 blocks x 4 k-steps x 64 lanes
+__host__ __device__ inline size_t frag_doubles(int d) { return (size_t)nblk16(d) * (nblk16(d) + 1) / 2 * 256; }
 
-__global__ __launch_bounds__(256) void k_cholesky(const double* __restrict__ cov, int d, double* __restrict__ ws) {
-  extern __shared__ double a[];  // d x d, row-major
+// Phase timestamps for tools/chol_probe.hip only (compiled out of the library).
+#ifdef M355_CHOL_PROBE
+__device__ long long g_chol_ticks[64];
+#define M355_TICK(n) do { if (threadIdx.x == 0 && blockIdx.x == 0) g_chol_ticks[n] = clock64(); } while (0)
+#else
+#define M355_TICK(n) do { } while (0)
+#endif
+
+M355_DEV double readlane_d(double v, int lane) {  // `lane` must be wave-uniform
+  const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, lane);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), lane);
+  return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+
+// sqrt(a) and 1/sqrt(a) from the hardware rsq seed (coupled Newton steps, ~1 ulp each); a <= 0 or
+// NaN gives NaN for both (a non-positive pivot poisons the factor, as the reference's does).
+M355_DEV void sqrt_rsqrt(double a, double& root, double& inv_root) {
+  const double y = __builtin_amdgcn_rsq(a);
+  double g = a * y, h = 0.5 * y;
+  double r = __builtin_fma(-h, g, 0.5);
+  g = __builtin_fma(g, r, g);
+  h = __builtin_fma(h, r, h);
+  g = __builtin_fma(__builtin_fma(-g, g, a), h, g);
+  r = __builtin_fma(-h, g, 0.5);
+  h = __builtin_fma(h, r, h);
+  const bool ok = a > 0.0;
+  root = ok ? g : kNaN;
+  inv_root = ok ? 2.0 * h : kNaN;
+}
+
+// Fragment of block (I, J), J <= I, k-step kk, lane l: element [row 16I + (l&15)][col 16J + (l>>4) + 4kk]
+// of -L (J < I) or of inv(L_II) (J == I): the A operand whose k index matches the D/B layout.
+//
+// Factorisation (256 threads; row i of the matrix belongs to thread i): the matrix is padded to
+// dp = 16*NB with an identity block.  Per 16-column panel J:
+//   A  U = A[:, panel] - L[:, :16J] L[panel, :16J]^T : the 16 columns are split over the wavefronts
+//      (each lane: its row against 4 or 8 columns, register accumulators; one conflict-free row read
+//      plus broadcast reads per k), result written back in place;
+//   B  the wavefront that owns rows 16J..16J+15 factors the panel in registers: column c takes its
+//      pivot and the multipliers L[16J+c][c'] from the owning lanes by v_readlane (no LDS, no
+//      barrier): l[c] = (u[c] - sum_{c'<c} l[c'] L[16J+c][c']) / sqrt(pivot);
+//   C  rows held by the other row wavefront (d > 64) do the same substitution against the 16x16
+//      diagonal block published through LDS.
+// Measured phase costs (tools/chol_probe.hip) are in DESIGN.md.
+constexpr int kCholThreads = 256;
+
+__global__ __launch_bounds__(kCholThreads) void k_cholesky(const double* __restrict__ cov, int d,
+                                                            double* __restrict__ ws, double* __restrict__ frags) {
+  extern __shared__ double a[];  // dp x S (S odd) | 16x16 diagonal block + 16 reciprocals | NB x 16 x 16 inverses | dp reciprocals
+  const int NB = nblk16(d);
+  const int dp = 16 * NB, S = dp + 1;
+  double* diag = a + (size_t)dp * S;
+  double* inv = diag + 272;
+  double* rdiag = inv + NB * 256;
   const double* src = cov + (size_t)blockIdx.x * d * d;
   double* dst = ws + (size_t)blockIdx.x * chol_stride(d);
-  for (int e = threadIdx.x; e < d * d; e += blockDim.x) a[e] = src[e];
+  const int t = threadIdx.x, wave = t >> 6;
+  // 2-D thread layout for the global <-> LDS copies: CW columns x (256 / CW) rows per step
+  const int cshift = dp <= 16 ? 4 : (dp <= 32 ? 5 : (dp <= 64 ? 6 : 7));
+  const int ccol = t & ((1 << cshift) - 1), crow0 = t >> cshift, crstep = kCholThreads >> cshift;
+  M355_TICK(0);
+  if (ccol < dp) {
+#pragma unroll 8
+    for (int r = crow0; r < dp; r += crstep)
+      a[r * S + ccol] = (r < d && ccol < d) ? src[r * d + ccol] : (r == ccol ? 1.0 : 0.0);
+  }
   __syncthreads();
-  for (int j = 0; j < d; ++j) {
-    // pivot and column scaling
-    const double piv = sqrt_(a[j * d + j]);  // NaN for a negative pivot
-    __syncthreads();
-    if (threadIdx.x == 0) a[j * d + j] = piv;
-    for (int i = j + 1 + threadIdx.x; i < d; i += blockDim.x) a[i * d + j] = a[i * d + j] / piv;
-    __syncthreads();
-    // trailing update of the lower triangle: a[i][k] -= a[i][j] * a[k][j], j < k <= i
-    const int m = d - j - 1;
-    for (int e = threadIdx.x; e < m * m; e += blockDim.x) {
-      const int i = j + 1 + e / m, k = j + 1 + e % m;
-      if (k <= i) a[i * d + k] = __builtin_fma(-a[i * d + j], a[k * d + j], a[i * d + k]);
+  M355_TICK(1);
+  const int lane = t & 63;
+  const int i = t;  // row owned in steps B / C (threads >= dp idle there)
+  double* ai = a + (size_t)(i < dp ? i : 0) * S;
+  for (int J = 0; J < NB; ++J) {
+    M355_TICK(2 + 4 * J);
+    const int c0 = 16 * J;
+    // A: 16x16 tiles (I, J), I >= J, dealt to the wavefronts; U_IJ = A_IJ - sum_{K<J} L_IK L_JK^T on MFMA
+    for (int I = J + wave; J > 0 && I < NB; I += kCholThreads / 64) {
+      double* cbase = a + (size_t)(16 * I + (lane >> 4)) * S + c0 + (lane & 15);  // D layout: row (l>>4)+4r, col l&15
+      d4_t acc;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[r] = cbase[4 * r * S];
+      const double* pa = a + (size_t)(16 * I + (lane & 15)) * S + (lane >> 4);  // A: L[16I + (l&15)][k]
+      const double* pb = a + (size_t)(c0 + (lane & 15)) * S + (lane >> 4);      // B: L[16J + (l&15)][k]
+      for (int k = 0; k < c0; k += 4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-pa[k], pb[k], acc, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) cbase[4 * r * S] = acc[r];
+    }
+    if (J > 0) __syncthreads();
+    M355_TICK(3 + 4 * J);
+    double u[16], l[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) l[c] = 0.0;
+    const bool mine = i >= c0 && i < dp;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) u[c] = mine ? ai[c0 + c] : 0.0;
+    if (wave == (c0 >> 6)) {  // B (wave-uniform branch)
+      const int base = c0 & 63;
+      const int r = (i & 63) - base;
+      double rinv[16];
+#pragma unroll
+      for (int c = 0; c < 16; ++c) {
+        double sacc = u[c];
+#pragma unroll
+        for (int cc = 0; cc < c; ++cc) sacc = __builtin_fma(-l[cc], readlane_d(l[cc], base + c), sacc);
+        double piv;
+        sqrt_rsqrt(readlane_d(sacc, base + c), piv, rinv[c]);
+        l[c] = (r == c) ? piv : (r > c ? sacc * rinv[c] : 0.0);
+      }
+      if (r >= 0 && r < 16) {
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+          diag[r * 16 + c] = l[c];
+          if (r == c) {
+            diag[256 + c] = rinv[c];
+            rdiag[c0 + c] = rinv[c];
+          }
+        }
+      }
+    }
+    if (dp > 64) {
+      __syncthreads();
+      M355_TICK(4 + 4 * J);
+      if (wave != (c0 >> 6) && wave < 2 && i >= c0 + 16 && i < dp) {  // C
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+          double sacc = u[c];
+#pragma unroll
+          for (int cc = 0; cc < c; ++cc) sacc = __builtin_fma(-l[cc], diag[c * 16 + cc], sacc);
+          l[c] = sacc * diag[256 + c];
+        }
+      }
+    }
+    if (mine) {
+#pragma unroll
+      for (int c = 0; c < 16; ++c) ai[c0 + c] = l[c];
     }
     __syncthreads();
+    M355_TICK(5 + 4 * J);
   }
-  for (int e = threadIdx.x; e < d * d; e += blockDim.x) {
-    const int i = e / d, k = e % d;
-    dst[e] = (k <= i) ? a[e] : 0.0;
+  M355_TICK(40);
+  if (ccol < d) {
+#pragma unroll 8
+    for (int r = crow0; r < d; r += crstep) dst[r * d + ccol] = (ccol <= r) ? a[r * S + ccol] : 0.0;
   }
-  for (int i = threadIdx.x; i < d; i += blockDim.x) dst[(size_t)d * d + i] = 1.0 / a[i * d + i];
-  if (threadIdx.x == 0) {
-    double s = 0.0;
-    for (int i = 0; i < d; ++i) s += flog(a[i * d + i]);  // log of a NaN / negative diag -> NaN
-    dst[(size_t)d * d + d] = 2.0 * s;
+  if (i < d) dst[(size_t)d * d + i] = 1.0 / ai[i];
+  {
+    // logdet = 2 * sum log(diag): per-row logs, then a fixed-order tree over the workgroup
+    double lg = (i < d) ? flog(ai[i]) : 0.0;  // log of a NaN diag -> NaN
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) lg += __shfl_down(lg, o, 64);
+    if ((t & 63) == 0) diag[wave] = lg;
+    __syncthreads();
+    if (t == 0) dst[(size_t)d * d + d] = 2.0 * (diag[0] + diag[1]);  // rows live in wavefronts 0 and 1 only
   }
+  M355_TICK(41);
+  if (frags == nullptr) return;
+  // inverse of each 16x16 lower-triangular diagonal block, one column per thread, in registers:
+  //   X[c][c] = 1/L[c][c],  X[r][c] = -(sum_{k=c}^{r-1} L[r][k] X[k][c]) / L[r][r]
+  if (t < dp) {
+    const int I = t >> 4, c = t & 15;
+    const double* Lb = a + (size_t)(16 * I) * S + 16 * I;
+    const double* rd = rdiag + 16 * I;
+    double x[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      double acc = 0.0;
+#pragma unroll
+      for (int k = 0; k < r; ++k) acc = __builtin_fma(Lb[r * S + k], (k >= c) ? x[k] : 0.0, acc);
+      x[r] = (r == c) ? rd[r] : (r > c ? -acc * rd[r] : 0.0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) inv[I * 256 + r * 16 + c] = x[r];
+  }
+  __syncthreads();
+  M355_TICK(42);
+  {
+    // thread = (k-step kk, lane l); blocks b = (I, J) walked in order
+    const int l = t & 63, kk = t >> 6;
+    const int r = l & 15, c = (l >> 4) + 4 * kk;
+    int e = t;
+    for (int I = 0; I < NB; ++I) {
+      for (int J = 0; J <= I; ++J, e += 256)
+        frags[e] = (J == I) ? inv[I * 256 + r * 16 + c] : -a[(16 * I + r) * S + 16 * J + c];
+    }
+  }
+  M355_TICK(43);
 }
 
 struct SolveArgs {
@@ -116,6 +291,137 @@ template <bool SHARED> __global__ __launch_bounds__(kSolveThreads) void k_solve(
   }
 }
 
+struct MfmaArgs {
+  const double* x;      // n x d row-major, contiguous, 16-byte aligned
+  const double* mu;     // d doubles (mu_rows 0) or n x d laid out like x
+  const double* frags;  // frag_doubles(d) doubles from k_cholesky
+  const double* chol;   // chol_stride(d) doubles (logdet at the end)
+  double* out;
+  long long n;
+  int d;
+  int mode;  // 0: quad, 1: mvnormal logpdf, 2: mvstudentt logpdf
+  double nu, c0;
+};
+
+constexpr int kMfmaWaves = 4;
+
+template <int NB, bool MU_ROWS> __global__ __launch_bounds__(64 * kMfmaWaves) void k_solve_mfma(const MfmaArgs a) {
+  constexpr int NBLK = NB * (NB + 1) / 2;
+  constexpr int S = 16 * NB + 4;  // staging row stride: the 64 lanes of a D-layout read hit each bank pair twice
+  constexpr int NJ = 2 * NB;      // 16-byte loads per lane per tile (16 obs x 16 NB doubles / 128)
+  extern __shared__ double lds[];
+  double* fr = lds;                   // NBLK * 256
+  double* mu_s = fr + NBLK * 256;     // 16 * NB (zero padded)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double* st = mu_s + 16 * NB + wave * (16 * S);  // this wavefront's 16 x S staging tile
+  const int d = a.d;
+  const int tile_elems = 16 * d;
+  const long long total = a.n * (long long)d;
+  const long long ntiles = (a.n + 15) / 16;
+  const long long tstride = (long long)gridDim.x * kMfmaWaves;
+  d2_t raw[NJ];
+  auto fetch = [&](long long tile) {
+    const long long base = tile * tile_elems;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int e = 128 * j + 2 * lane;
+      const long long g = base + e;
+      d2_t v = {0.0, 0.0};
+      if (e < tile_elems) {
+        if (g + 1 < total) {
+          v = __builtin_nontemporal_load(reinterpret_cast<const d2_t*>(a.x + g));
+          if (MU_ROWS) v -= __builtin_nontemporal_load(reinterpret_cast<const d2_t*>(a.mu + g));
+        } else if (g < total) {
+          v.x = a.x[g];
+          if (MU_ROWS) v.x -= a.mu[g];
+        }
+      }
+      raw[j] = v;
+    }
+  };
+  M355_TICK(50);
+  long long tile = (long long)blockIdx.x * kMfmaWaves + wave;
+  if (tile < ntiles) fetch(tile);  // first tile in flight while the operand fragments are staged
+  {
+    double tmp[NBLK];
+#pragma unroll
+    for (int b = 0; b < NBLK; ++b) tmp[b] = a.frags[b * 256 + threadIdx.x];
+#pragma unroll
+    for (int b = 0; b < NBLK; ++b) fr[b * 256 + threadIdx.x] = tmp[b];
+  }
+  for (int e = threadIdx.x; e < 16 * NB; e += blockDim.x) mu_s[e] = (!MU_ROWS && e < d) ? a.mu[e] : 0.0;
+  for (int e = lane; e < 16 * S; e += 64) st[e] = 0.0;  // padding columns stay zero for the whole kernel
+  __syncthreads();
+
+  // flat element e = 128 j + 2 lane (+1) of a tile -> staging offset and mean, fixed for the kernel.
+  // e / d through a float reciprocal: exact here (e < 2048, d <= 128: (e + 0.5) / d is never within
+  // float rounding of an integer).
+  int off0[NJ], off1[NJ];
+  double m0[NJ], m1[NJ];
+  const float invd = 1.0f / (float)d;
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int e = 128 * j + 2 * lane;
+    const int o0 = (int)(((float)e + 0.5f) * invd), c0 = e - o0 * d;
+    const int o1 = (int)(((float)e + 1.5f) * invd), c1 = (e + 1) - o1 * d;
+    off0[j] = e < tile_elems ? o0 * S + c0 : -1;
+    off1[j] = (e + 1) < tile_elems ? o1 * S + c1 : -1;
+    m0[j] = e < tile_elems ? mu_s[c0] : 0.0;
+    m1[j] = (e + 1) < tile_elems ? mu_s[c1] : 0.0;
+  }
+  const double logdet = a.chol[(size_t)d * d + d];
+  const int rbase = (lane & 15) * S + (lane >> 4);
+  M355_TICK(51);
+  int tk = 52;
+  for (; tile < ntiles; tile += tstride) {
+    M355_TICK(tk); ++tk;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      if (off0[j] >= 0) st[off0[j]] = raw[j].x - m0[j];
+      if (off1[j] >= 0) st[off1[j]] = raw[j].y - m1[j];
+    }
+    M355_TICK(tk); ++tk;
+    if (tile + tstride < ntiles) fetch(tile + tstride);  // in flight during the MFMA chain below
+    __builtin_amdgcn_wave_barrier();
+    d4_t Y[NB];
+    double quad = 0.0;
+#pragma unroll
+    for (int I = 0; I < NB; ++I) {
+      d4_t acc;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[r] = st[rbase + 16 * I + 4 * r];
+#pragma unroll
+      for (int J = 0; J < I; ++J) {
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(fr[((I * (I + 1) / 2 + J) * 4 + kk) * 64 + lane], Y[J][kk], acc, 0, 0, 0);
+      }
+      d4_t y = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk)
+        y = __builtin_amdgcn_mfma_f64_16x16x4f64(fr[((I * (I + 1) / 2 + I) * 4 + kk) * 64 + lane], acc[kk], y, 0, 0, 0);
+      Y[I] = y;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) quad = __builtin_fma(y[r], y[r], quad);
+    }
+    __builtin_amdgcn_wave_barrier();
+    M355_TICK(tk); ++tk;
+    // lanes l, l+16, l+32, l+48 hold the four row groups of observation l & 15
+    quad += __shfl_xor(quad, 16, 64);
+    quad += __shfl_xor(quad, 32, 64);
+    const long long r = tile * 16 + lane;
+    if (lane < 16 && r < a.n) {
+      double v = quad;
+      if (a.mode == 1) {
+        v = -0.5 * (a.c0 + logdet + quad);  // mvnormal.py:82-83
+      } else if (a.mode == 2) {
+        v = a.c0 - 0.5 * (a.nu + (double)d) * flog1p(quad / a.nu) - 0.5 * logdet;  // mvstudentt.py:62-64
+      }
+      a.out[r] = v;
+    }
+  }
+}
+
 // out[b] = scale * sum_{j<m} v[b*m + j] + offset[b % noff]   (matrixnormal's Frobenius norm and normaliser)
 __global__ __launch_bounds__(256) void k_rowsum(const double* __restrict__ v, long long nb, int m, double scale,
                                                 const double* __restrict__ offset, long long noff,
@@ -145,15 +451,44 @@ int launched() {
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? M355_OK : fail(M355_ERR_LAUNCH, "HIP launch failed: %s", hipGetErrorString(e));
 }
-int run_cholesky(const double* cov, long long ncov, int d, double* ws, hipStream_t s) {
-  const size_t lds = (size_t)d * d * sizeof(double);
-  if (lds > 64 * 1024) {  // up to 128 KiB of the CU's 160 KiB LDS for d = 128
+int run_cholesky(const double* cov, long long ncov, int d, double* ws, double* frags, hipStream_t s) {
+  const int threads = m355::kCholThreads;
+  const int dp = 16 * m355::nblk16(d);
+  const size_t lds = ((size_t)dp * (dp + 1) + 272 + (size_t)m355::nblk16(d) * 256 + dp) * sizeof(double);
+  if (lds > 64 * 1024) {  // up to ~148 KiB of the CU's 160 KiB LDS for d = 128
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(m355::k_cholesky),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return fail(M355_ERR_LAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
   }
-  hipLaunchKernelGGL(m355::k_cholesky, dim3((unsigned)ncov), dim3(256), (size_t)d * d * sizeof(double), s, cov, d, ws);
+  hipLaunchKernelGGL(m355::k_cholesky, dim3((unsigned)ncov), dim3(threads), lds, s, cov, d, ws, frags);
   return launched();
+}
+template <int NB, bool MU_ROWS> int launch_mfma(const m355::MfmaArgs& a, hipStream_t s) {
+  const size_t lds = ((size_t)NB * (NB + 1) / 2 * 256 + 16 * NB + (size_t)m355::kMfmaWaves * 16 * (16 * NB + 4)) * sizeof(double);
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(m355::k_solve_mfma<NB, MU_ROWS>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return fail(M355_ERR_LAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+  }
+  const long long ntiles = (a.n + 15) / 16;
+  long long blocks = (ntiles + m355::kMfmaWaves - 1) / m355::kMfmaWaves;
+  long long cap = 2 * 256;  // two workgroups per CU: every wavefront sees >= 2 tiles and prefetches
+  if (const char* e = getenv("M355_MVN_BLOCKS")) cap = atoll(e);
+  if (blocks > cap) blocks = cap;
+  hipLaunchKernelGGL((m355::k_solve_mfma<NB, MU_ROWS>), dim3((unsigned)blocks), dim3(64 * m355::kMfmaWaves), lds, s, a);
+  return launched();
+}
+template <bool MU_ROWS> int run_mfma(const m355::MfmaArgs& a, hipStream_t s) {
+  switch (m355::nblk16(a.d)) {
+    case 1: return launch_mfma<1, MU_ROWS>(a, s);
+    case 2: return launch_mfma<2, MU_ROWS>(a, s);
+    case 3: return launch_mfma<3, MU_ROWS>(a, s);
+    case 4: return launch_mfma<4, MU_ROWS>(a, s);
+    case 5: return launch_mfma<5, MU_ROWS>(a, s);
+    case 6: return launch_mfma<6, MU_ROWS>(a, s);
+    case 7: return launch_mfma<7, MU_ROWS>(a, s);
+    default: return launch_mfma<8, MU_ROWS>(a, s);
+  }
 }
 int run_solve(const m355::SolveArgs& a, bool shared, hipStream_t s) {
   const long long blocks = (a.n + m355::kSolveThreads - 1) / m355::kSolveThreads;
@@ -165,7 +500,8 @@ int run_solve(const m355::SolveArgs& a, bool shared, hipStream_t s) {
 }  // namespace
 
 extern "C" size_t m355_mvn_workspace_bytes(int d, int64_t ncov) {
-  return (size_t)ncov * m355::chol_stride(d) * sizeof(double);
+  // the factors, plus the MFMA operand fragments of a shared covariance
+  return ((size_t)ncov * m355::chol_stride(d) + (ncov == 1 ? m355::frag_doubles(d) : 0)) * sizeof(double);
 }
 
 extern "C" int m355_mvn_logpdf(int kind, int64_t n, int d, const double* x, const double* mu, int64_t mu_stride,
@@ -182,8 +518,18 @@ extern "C" int m355_mvn_logpdf(int kind, int64_t n, int d, const double* x, cons
                  m355_mvn_workspace_bytes(d, ncov));
   hipStream_t s = static_cast<hipStream_t>(stream);
   double* ws = static_cast<double*>(workspace);
-  int rc = run_cholesky(cov, ncov, d, ws, s);
+  auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  const bool mfma = ncov == 1 && al16(x) && (mu_stride == 0 || (mu_stride == d && al16(mu)));
+  double* frags = mfma ? ws + chol_stride(d) : nullptr;
+  int rc = run_cholesky(cov, ncov, d, ws, frags, s);
   if (rc != M355_OK) return rc;
+  const double lognorm_n = (double)d * 1.8378770664093454836;  // k*log(2 pi)
+  // gammaln((nu+k)/2) - gammaln(nu/2) - 0.5*k*log(nu*pi)   (mvstudentt.py:62)
+  const double lognorm_t = kind == 1 ? lgamma((nu + d) / 2.0) - lgamma(nu / 2.0) - 0.5 * d * log(nu * 3.14159265358979323846) : 0.0;
+  if (mfma) {
+    MfmaArgs m{x, mu, frags, ws, out, (long long)n, d, kind == 0 ? 1 : 2, nu, kind == 0 ? lognorm_n : lognorm_t};
+    return mu_stride == 0 ? run_mfma<false>(m, s) : run_mfma<true>(m, s);
+  }
   SolveArgs a{};
   a.x = x;
   a.mu = mu;
@@ -201,15 +547,9 @@ extern "C" int m355_mvn_logpdf(int kind, int64_t n, int d, const double* x, cons
   a.out = out;
   a.n = n;
   a.d = d;
-  if (kind == 0) {
-    a.mode = 1;
-    a.c0 = (double)d * 1.8378770664093454836;  // k*log(2 pi)
-  } else {
-    a.mode = 2;
-    a.nu = nu;
-    // gammaln((nu+k)/2) - gammaln(nu/2) - 0.5*k*log(nu*pi)   (mvstudentt.py:62)
-    a.c0 = lgamma((nu + d) / 2.0) - lgamma(nu / 2.0) - 0.5 * d * log(nu * 3.14159265358979323846);
-  }
+  a.mode = kind == 0 ? 1 : 2;
+  a.nu = nu;
+  a.c0 = kind == 0 ? lognorm_n : lognorm_t;
   return run_solve(a, ncov == 1, s);
 }
 
@@ -236,9 +576,9 @@ extern "C" int m355_matrixnormal_logpdf(int64_t nbatch, int m, int n, const doub
   double* Y = wsV + (size_t)ncol * chol_stride(n);
   double* rowq = Y + (size_t)nbatch * m * n;
   double* off = rowq + (size_t)nbatch * m;
-  int rc = run_cholesky(rowcov, nrow, m, wsU, s);
+  int rc = run_cholesky(rowcov, nrow, m, wsU, nullptr, s);
   if (rc != M355_OK) return rc;
-  rc = run_cholesky(colcov, ncol, n, wsV, s);
+  rc = run_cholesky(colcov, ncol, n, wsV, nullptr, s);
   if (rc != M355_OK) return rc;
   // Y = L_U^-1 (X - M): the n columns of each m x n matrix are observations of dimension m
   SolveArgs a{};
