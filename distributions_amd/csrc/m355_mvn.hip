@@ -373,6 +373,7 @@ template <int NB, bool MU_ROWS> __global__ __launch_bounds__(64 * kMfmaWaves) vo
   const int rbase = (lane & 15) * S + (lane >> 4);
   M355_TICK(51);
   int tk = 52;
+  (void)tk;
   for (; tile < ntiles; tile += tstride) {
     M355_TICK(tk); ++tk;
 #pragma unroll

@@ -122,12 +122,21 @@ M355_DEV double log_gamma_kernel(double a, double x, double lga) {
 
 constexpr int kMaxIter = 100000;
 
+// Iteration counting for the host-side convergence probe (tools/iter_probe.cpp); no-op elsewhere.
+#if defined(M355_ITER_PROBE) && !defined(__HIPCC__)
+extern long long g_m355_iters;
+#define M355_ITER() (++g_m355_iters)
+#else
+#define M355_ITER() ((void)0)
+#endif
+
 // DLMF 8.11.4:  P(a,x) = x^a e^-x / Gamma(a+1) * sum_{n>=0} x^n / ((a+1)...(a+n)).
 M355_DEV_HEAVY double gammainc_series(double a, double x, double lga) {
   const double lk = log_gamma_kernel(a, x, lga);
   if (lk < kMinLog) return 0.0;
   double term = 1.0, sum = 1.0, r = a;
   for (int n = 0; n < kMaxIter; ++n) {
+    M355_ITER();
     r += 1.0;
     term *= fdiv(x, r);
     sum += term;
@@ -146,6 +155,7 @@ M355_DEV_HEAVY double gammaincc_cf(double a, double x, double lga) {
   double p2 = 1.0, q2 = x, p1 = x + 1.0, q1 = z * x;
   double ans = fdiv(p1, q1);
   for (int n = 0; n < kMaxIter; ++n) {
+    M355_ITER();
     c += 1.0;
     y += 1.0;
     z += 2.0;
@@ -179,6 +189,7 @@ M355_DEV_HEAVY double gammaincc_cf(double a, double x, double lga) {
 M355_DEV_HEAVY double gammaincc_series(double a, double x, double lga) {
   double fac = 1.0, sum = 0.0;
   for (int n = 1; n < kMaxIter; ++n) {
+    M355_ITER();
     fac *= -x / (double)n;
     const double term = fdiv(fac, a + (double)n);
     sum += term;
@@ -226,6 +237,13 @@ M355_DEV double norm_quantile_guess(double p) {
                             1.0 + t * (1.432788 + t * (0.189269 + t * 0.001308)));
   return p < 0.5 ? -v : v;
 }
+
+// Root finders stop after the first step whose relative size is below kRootStep: the iterations
+// are at least quadratically convergent (Newton on log-tail, Halley elsewhere), so the error left
+// after that step is ~ kRootStep^2 * curvature <= 1e-16.  (Waiting for a step of a few ulp instead
+// makes the iterate bounce in the rounding noise of the forward function until the bracket is
+// exhausted: measured 6x the work at isolated q, tools/iter_probe.cpp.)
+constexpr double kRootStep = 2e-9;
 
 // Inverse of P(a, .) (pt.gammaincinv): safeguarded Halley iteration on the smaller tail.
 M355_DEV_HEAVY double gammaincinv_p(double a, double p, double lga) {
@@ -289,7 +307,13 @@ M355_DEV_HEAVY double gammaincinv_p(double a, double p, double lga) {
         xn = x - x * ((den > 0.5 && den < 2.0) ? fdiv(dx_rel, den) : dx_rel);
       }
     }
+    if (xn > 0.0 && __builtin_fabs(xn - x) <= kRootStep * x) {  // converged (also when xn rounds onto a bracket end)
+      x = xn;
+      break;
+    }
+    bool safeguarded = false;
     if (!(xn > lo) || !(xn < hi)) {
+      safeguarded = true;
       if (hi == kInf) {
         xn = (lo > 0.0 ? lo : x) * grow + 1.0;
         grow *= grow;
@@ -303,7 +327,9 @@ M355_DEV_HEAVY double gammaincinv_p(double a, double p, double lga) {
     }
     const double dx = __builtin_fabs(xn - x);
     x = xn;
-    if (dx <= 4.0 * kEps * x) break;
+    // a small Newton / Halley step squares (or cubes) the error it leaves: converged.  Safeguard
+    // (bisection-like) steps only converge linearly and run down to a few ulp.
+    if (dx <= (safeguarded ? 4.0 * kEps : kRootStep) * x) break;
   }
   return x;
 }
@@ -325,6 +351,7 @@ M355_DEV_HEAVY double betainc_pseries(double a, double b, double x, double lbeta
   double s = 0.0, n = 2.0;
   const double z = kEps * ai;
   for (int it = 0; it < kMaxIter && __builtin_fabs(v) > z; ++it) {
+    M355_ITER();
     const double u = fdiv((n - b) * x, n);
     t *= u;
     v = fdiv(t, a + n);
@@ -350,6 +377,7 @@ M355_DEV_HEAVY double betainc_cf(double a, double b, double x) {
   d = rcp(d);
   double h = d;
   for (int m = 1; m < kMaxIter; ++m) {
+    M355_ITER();
     const double dm = (double)m;
     const double m2 = 2.0 * dm;
     double aa = fdiv(dm * (b - dm) * x, (qam + m2) * (a + m2));
@@ -466,7 +494,13 @@ M355_DEV_HEAVY double betaincinv_(double a, double b, double p, double lbeta) {
         tn = t - ((den > 0.5 && den < 2.0) ? fdiv(nstep, den) : nstep);
       }
     }
+    if (tn > 0.0 && __builtin_fabs(tn - t) <= kRootStep * t) {  // converged (also when tn rounds onto a bracket end)
+      t = tn;
+      break;
+    }
+    bool safeguarded = false;
     if (!(tn > lo) || !(tn < hi)) {
+      safeguarded = true;
       if (lo == 0.0) {
         tn = hi * shrink;
         shrink *= shrink;
@@ -477,7 +511,7 @@ M355_DEV_HEAVY double betaincinv_(double a, double b, double p, double lbeta) {
     }
     const double dt = __builtin_fabs(tn - t);
     t = tn;
-    if (dt <= 4.0 * kEps * t) break;
+    if (dt <= (safeguarded ? 4.0 * kEps : kRootStep) * t) break;  // as in gammaincinv_p
   }
   return rep_y ? 1.0 - t : t;
 }
