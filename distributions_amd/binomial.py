@@ -36,6 +36,16 @@ def sf(x, n, p):
     return _elemwise("binomial", "sf", x, n, p)
 
 
+def ppf(q, n, p):
+    """binomial.py:49-51 of the reference (find_ppf_discrete, optimization.py:102-129, run per element)."""
+    return _elemwise("binomial", "ppf", q, n, p)
+
+
+def isf(q, n, p):
+    """binomial.py:58-59 of the reference."""
+    return _elemwise("binomial", "isf", q, n, p)
+
+
 def sum_logpdf(x, n, p):
     """sum(logpdf(x, n, p)) fused in one pass (the reference spells it pt.sum(logpdf(...)))."""
     return _sumlogp("binomial", "logpdf", x, n, p)

@@ -54,13 +54,6 @@ __global__ __launch_bounds__(256) void k_cat_tables(const double* __restrict__ p
   }
 }
 
-// ppf_bounds_disc (helper.py:57-87)
-M355_DEV double ppf_bounds_disc(double v, double q, double lower, double upper) {
-  double r = (q == 1.0) ? upper : v;
-  r = (q == 0.0) ? lower - 1.0 : r;
-  return ((q < 0.0) | (q > 1.0)) ? kNaN : r;
-}
-
 template <bool LDS>
 __global__ __launch_bounds__(kBlock) void k_categorical(int fn, const void* __restrict__ x, int xdt,
                                                         const double* __restrict__ ws, int k,

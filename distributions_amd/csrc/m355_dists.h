@@ -243,6 +243,39 @@ template <> struct Dist<M355_STUDENTT> {
   }
 };
 
+// helper.py:57-87
+M355_DEV double ppf_bounds_disc(double v, double q, double lower, double upper) {
+  double r = (q == 1.0) ? upper : v;
+  r = (q == 0.0) ? lower - 1.0 : r;
+  return ((q < 0.0) | (q > 1.0)) ? kNaN : r;
+}
+
+// find_ppf_discrete (optimization.py:102-129): integer Newton / unit-step search from floor(x0),
+// max_iter = 100, tol = 1e-7.  The reference iterates the whole batch until every element is
+// `found`; a found element is a fixed point of the step (x_new = x_int), so a per-lane loop with
+// early exit gives the same values.  Only q in (0, 1) reaches the loop result: every other q is
+// decided by ppf_bounds_disc (a NaN q turns the iterate into NaN in the first step).
+template <class CDF, class PMF>
+M355_DEV double find_ppf_discrete(double q, double x0, double lower, double upper, CDF cdf, PMF pmf) {
+  double x = floor_(x0);
+  if (!(q == q)) return kNaN;
+  if ((q > 0.0) & (q < 1.0)) {
+    for (int it = 0; it < 100; ++it) {
+      const double xi = floor_(x);
+      const double c = cdf(xi), cm = cdf(xi - 1.0);
+      x = xi;
+      if ((c >= q - 1e-7) & (cm < q)) break;  // found
+      const double pm = pmf(xi);
+      const double delta = (c - q) / (pm > 1e-10 ? pm : 1e-10);
+      const double sgn = (c > q) ? 1.0 : ((c < q) ? -1.0 : 0.0);
+      const double step = (__builtin_fabs(delta) < 0.5) ? sgn : floor_(delta);
+      const double xn = xi - step;
+      x = xn < lower ? lower : (xn > upper ? upper : xn);  // pt.clip
+    }
+  }
+  return ppf_bounds_disc(x, q, lower, upper);
+}
+
 // -------------------------------------------------------------------------------------- poisson
 template <> struct Dist<M355_POISSON> {
   static constexpr int NP = 1;
@@ -273,6 +306,11 @@ template <> struct Dist<M355_POISSON> {
     if constexpr (FN == M355_SF) return sf(x, k);
     if constexpr (FN == M355_LOGCDF) return flog(cdf(x, k));  // poisson.py:74-75
     if constexpr (FN == M355_LOGSF) return flog(sf(x, k));    // poisson.py:78-79
+    if constexpr (FN == M355_PPF || FN == M355_ISF) {         // poisson.py:53-55, 62-63
+      const double q = (FN == M355_ISF) ? 1.0 - x : x;
+      return find_ppf_discrete(q, k.mu, 0.0, kInf, [&](double v) { return cdf(v, k); },
+                               [&](double v) { return exp_(logpdf(v, k)); });
+    }
     return kNaN;
   }
 };
@@ -308,15 +346,18 @@ template <> struct Dist<M355_BINOMIAL> {
     if constexpr (FN == M355_SF) return 1.0 - cdf(x, k);        // binomial.py:54-55
     if constexpr (FN == M355_LOGCDF) return flog(cdf(x, k));    // binomial.py:78-79
     if constexpr (FN == M355_LOGSF) return flog1p(-cdf(x, k));  // binomial.py:82-83
+    if constexpr (FN == M355_PPF || FN == M355_ISF) {           // binomial.py:49-51, 58-59 (x0 = mean = n p)
+      const double q = (FN == M355_ISF) ? 1.0 - x : x;
+      return find_ppf_discrete(q, k.n * k.p, 0.0, k.n, [&](double v) { return cdf(v, k); },
+                               [&](double v) { return exp_(logpdf(v, k)); });
+    }
     return kNaN;
   }
 };
 
-// Which (dist, fn) pairs exist on the path (poisson/binomial ppf/isf use find_ppf_discrete:
-// SURVEY.md 8(f) rank 2, not built yet).
+// Which (dist, fn) pairs exist on the path: all eight functions of all six distributions.
 constexpr bool supported(int dist, int fn) {
   if (fn < 0 || fn > M355_ISF) return false;
-  if (dist == M355_POISSON || dist == M355_BINOMIAL) return fn != M355_PPF && fn != M355_ISF;
   return dist >= M355_NORMAL && dist <= M355_BINOMIAL;
 }
 

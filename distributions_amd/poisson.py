@@ -36,6 +36,16 @@ def sf(x, mu):
     return _elemwise("poisson", "sf", x, mu)
 
 
+def ppf(q, mu):
+    """poisson.py:53-55 of the reference (find_ppf_discrete, optimization.py:102-129, run per element)."""
+    return _elemwise("poisson", "ppf", q, mu)
+
+
+def isf(q, mu):
+    """poisson.py:62-63 of the reference."""
+    return _elemwise("poisson", "isf", q, mu)
+
+
 def sum_logpdf(x, mu):
     """sum(logpdf(x, mu)) fused in one pass (the reference spells it pt.sum(logpdf(...)))."""
     return _sumlogp("poisson", "logpdf", x, mu)

@@ -425,6 +425,48 @@ def binomial_pdf(x, n, p):
         return np.exp(binomial_logpdf(x, n, p))
 
 
+# --------------------------------------------------------------------------- discrete ppf
+def find_ppf_discrete(q, x0, lower, upper, cdf_func, pmf_func, *params, max_iter=100, tol=1e-7):
+    """optimization.py:102-129: batch iteration with `until(all(found))`."""
+    q = np.asarray(q, dtype=_F)
+    x = np.floor(x0) + np.zeros_like(q)
+    with _quiet():
+        for _ in range(max_iter):
+            x_int = np.floor(x)
+            cdf_val = cdf_func(x_int, *params)
+            cdf_minus = cdf_func(x_int - 1, *params)
+            found = (cdf_val >= q - tol) & (cdf_minus < q)
+            pmf_val = np.maximum(pmf_func(x_int, *params), 1e-10)
+            delta = (cdf_val - q) / pmf_val
+            delta_d = np.where(np.abs(delta) < 0.5, np.sign(cdf_val - q), np.floor(delta))
+            x_new = x_int - delta_d
+            x_new = np.where(x_new < lower, lower, np.where(x_new > upper, upper, x_new))  # pt.clip keeps NaN
+            x = np.where(found, x_int, x_new)
+            if np.all(found):
+                break
+    return ppf_bounds_disc(x, q, lower, upper)
+
+
+def poisson_ppf(q, mu):
+    """poisson.py:53-55."""
+    return find_ppf_discrete(q, mu, 0, np.inf, poisson_cdf, poisson_pdf, mu)
+
+
+def poisson_isf(q, mu):
+    """poisson.py:62-63."""
+    return poisson_ppf(1.0 - np.asarray(q, dtype=_F), mu)
+
+
+def binomial_ppf(q, n, p):
+    """binomial.py:49-51 (x0 = mean = n p)."""
+    return find_ppf_discrete(q, n * p, 0, n, binomial_cdf, binomial_pdf, n, p)
+
+
+def binomial_isf(q, n, p):
+    """binomial.py:58-59."""
+    return binomial_ppf(1.0 - np.asarray(q, dtype=_F), n, p)
+
+
 # --------------------------------------------------------------------------- multivariate
 def _chol_lower(cov):
     cov = np.asarray(cov, dtype=_F)

@@ -21,8 +21,8 @@ FNS = {
     "gamma": ["logpdf", "logcdf", "logsf", "pdf", "cdf", "sf", "ppf", "isf"],
     "beta": ["logpdf", "logcdf", "logsf", "pdf", "cdf", "sf", "ppf", "isf"],
     "studentt": ["logpdf", "logcdf", "logsf", "pdf", "cdf", "sf", "ppf", "isf"],
-    "poisson": ["logpdf", "logcdf", "logsf", "pdf", "cdf", "sf"],
-    "binomial": ["logpdf", "logcdf", "logsf", "pdf", "cdf", "sf"],
+    "poisson": ["logpdf", "logcdf", "logsf", "pdf", "cdf", "sf", "ppf", "isf"],
+    "binomial": ["logpdf", "logcdf", "logsf", "pdf", "cdf", "sf", "ppf", "isf"],
 }
 
 

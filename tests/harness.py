@@ -95,10 +95,10 @@ def grids():
         g.append(("studentt", stats.t, [nu, mu, sigma], {"df": nu, "loc": mu, "scale": sigma},
                   (-inf, inf), {}))
     for mu in [2.0, 0.01, 100.0]:
-        g.append(("poisson", stats.poisson, [mu], {"mu": mu}, (0, inf), {"skip_isf": True}))
+        g.append(("poisson", stats.poisson, [mu], {"mu": mu}, (0, inf), {}))
     for n, p, lrt in [(4, 0.4, 1e-6), (10, 0.3, 1e-6), (100, 0.01, 1e-6), (20, 0.8, 1e-2)]:
         g.append(("binomial", stats.binom, [n, p], {"n": n, "p": p}, (0, n),
-                  {"skip_isf": True, "logsf_rtol": lrt}))
+                  {"logsf_rtol": lrt}))
     return g
 
 

@@ -40,7 +40,7 @@ def test_argument_validation_without_gpu():
     P = ctypes.POINTER(D.Operand)
     assert lib.m355_elemwise(99, 0, 0, 4, ctypes.byref(op), 2, ctypes.cast(params, P), None, None) == -1
     assert b"unknown distribution" in lib.m355_last_error()
-    assert lib.m355_elemwise(4, 3, 0, 4, ctypes.byref(op), 1, ctypes.cast(params, P), None, None) == -2  # poisson.ppf
+    assert lib.m355_elemwise(4, 8, 0, 4, ctypes.byref(op), 1, ctypes.cast(params, P), None, None) == -2  # no such fn
     assert lib.m355_elemwise(0, 0, 0, 4, ctypes.byref(op), 3, ctypes.cast(params, P), None, None) == -1  # nparams
     assert lib.m355_elemwise(0, 0, 0, -1, ctypes.byref(op), 2, ctypes.cast(params, P), None, None) == -1
     assert lib.m355_elemwise(0, 0, 0, 0, ctypes.byref(op), 2, ctypes.cast(params, P), None, None) == 0  # empty

@@ -69,8 +69,8 @@ HOST_FNS = {
     "gamma": list(FN),
     "beta": list(FN),
     "studentt": list(FN),
-    "poisson": ["logpdf", "pdf", "cdf", "sf", "logcdf", "logsf"],
-    "binomial": ["logpdf", "pdf", "cdf", "sf", "logcdf", "logsf"],
+    "poisson": ["logpdf", "pdf", "cdf", "sf", "logcdf", "logsf", "ppf", "isf"],
+    "binomial": ["logpdf", "pdf", "cdf", "sf", "logcdf", "logsf", "ppf", "isf"],
 }
 
 
