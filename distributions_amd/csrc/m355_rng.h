@@ -23,8 +23,11 @@ M355_HD unsigned mulhi32(unsigned a, unsigned b) { return (unsigned)(((unsigned 
 M355_HD Philox philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1) {
 #pragma unroll
   for (int r = 0; r < 10; ++r) {
-    const unsigned hi0 = mulhi32(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-    const unsigned hi1 = mulhi32(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+    // one 32x32->64 multiply per word pair (v_mad_u64_u32) instead of separate mul_hi / mul_lo
+    const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0;
+    const unsigned long long p1 = (unsigned long long)0xCD9E8D57u * c2;
+    const unsigned hi0 = (unsigned)(p0 >> 32), lo0 = (unsigned)p0;
+    const unsigned hi1 = (unsigned)(p1 >> 32), lo1 = (unsigned)p1;
     c0 = hi1 ^ c1 ^ k0;
     c1 = lo1;
     c2 = hi0 ^ c3 ^ k1;
@@ -162,6 +165,34 @@ M355_DEV double lfactorial(double k) {
   return (z - 0.5) * flog_stream(z) - z + kLogSqrt2Pi + stirling_corr(z);
 }
 
+// PTRS (Hoermann 1993, "The transformed rejection method for generating Poisson random
+// variables"), mu >= 10: the mu-only constants and one attempt.  Shared by the per-lane loop
+// (sample_poisson) and the compacting kernel (k_rvs_compact), so both produce the same draw for the
+// same (element, attempt) counters.
+struct PtrsK {
+  double mu, loglam, b, a, vr, log_invalpha;
+};
+M355_DEV PtrsK ptrs_setup(double mu) {
+  PtrsK c;
+  const double slam = fsqrt(mu);
+  c.mu = mu;
+  c.loglam = flog_stream(mu);
+  c.b = 0.931 + 2.53 * slam;
+  c.a = -0.059 + 0.02483 * c.b;
+  c.log_invalpha = flog_stream(1.1239 + 1.1328 / (c.b - 3.4));
+  c.vr = 0.9277 - 3.6224 / (c.b - 2.0);
+  return c;
+}
+// One PTRS attempt from the uniform pair (u1, v): true = accepted, k holds the draw.
+M355_DEV bool ptrs_attempt(const PtrsK& c, double u1, double v, double& k) {
+  const double u = u1 - 0.5;
+  const double us = 0.5 - __builtin_fabs(u);
+  k = floor_((2.0 * c.a / us + c.b) * u + c.mu + 0.43);
+  if (us >= 0.07 && v <= c.vr) return true;
+  if (k < 0.0 || (us < 0.013 && v > us)) return false;
+  return flog_stream(v) + c.log_invalpha - flog_stream(c.a / (us * us) + c.b) <= -c.mu + k * c.loglam - lfactorial(k);
+}
+
 // Poisson(mu) as a double holding an integer.  mu == 0 -> 0; mu < 0 or NaN -> NaN.
 M355_DEV double sample_poisson(RngState& st, double mu) {
   if (!(mu >= 0.0)) return kNaN;
@@ -178,22 +209,12 @@ M355_DEV double sample_poisson(RngState& st, double mu) {
     }
     return k;
   }
-  // PTRS (Hoermann 1993, "The transformed rejection method for generating Poisson random variables")
-  const double slam = fsqrt(mu), loglam = flog_stream(mu);
-  const double b = 0.931 + 2.53 * slam;
-  const double a = -0.059 + 0.02483 * b;
-  const double invalpha = 1.1239 + 1.1328 / (b - 3.4);
-  const double vr = 0.9277 - 3.6224 / (b - 2.0);
+  const PtrsK c = ptrs_setup(mu);
   double k = floor_(mu);
   for (int it = 0; it < kMaxAttempts; ++it) {
     double u1, v;
     next_pair(st, u1, v);
-    const double u = u1 - 0.5;
-    const double us = 0.5 - __builtin_fabs(u);
-    k = floor_((2.0 * a / us + b) * u + mu + 0.43);
-    if (us >= 0.07 && v <= vr) break;
-    if (k < 0.0 || (us < 0.013 && v > us)) continue;
-    if (flog_stream(v) + flog_stream(invalpha) - flog_stream(a / (us * us) + b) <= -mu + k * loglam - lfactorial(k)) break;
+    if (ptrs_attempt(c, u1, v, k)) break;
   }
   return k;
 }
@@ -210,6 +231,42 @@ M355_DEV double stirling_tail(double k) {
   return (1.0 / 12.0 - (1.0 / 360.0 - 1.0 / 1260.0 / kp1sq) / kp1sq) / kp1;
 }
 
+// BTRS (Hoermann 1993, "The generation of binomial random variates"), n*min(p,1-p) >= 10: the
+// parameter-only constants and one attempt (shared like PTRS above).
+struct BtrsK {
+  double n, r, b, a, c, vr, alpha, m, hm;
+  bool flip;
+};
+M355_DEV BtrsK btrs_setup(double n, double p) {
+  BtrsK k;
+  k.flip = p > 0.5;
+  const double pp = k.flip ? 1.0 - p : p;
+  const double q = 1.0 - pp;
+  const double spq = fsqrt(n * pp * q);
+  k.n = n;
+  k.b = 1.15 + 2.53 * spq;
+  k.a = -0.0873 + 0.0248 * k.b + 0.01 * pp;
+  k.c = n * pp + 0.5;
+  k.vr = 0.92 - 4.2 / k.b;
+  k.r = pp / q;
+  k.alpha = (2.83 + 5.1 / k.b) * spq;
+  k.m = floor_((n + 1.0) * pp);
+  // the k-independent part of the acceptance bound
+  k.hm = (k.m + 0.5) * flog_stream((k.m + 1.0) / (k.r * (n - k.m + 1.0))) + stirling_tail(k.m) + stirling_tail(n - k.m);
+  return k;
+}
+M355_DEV bool btrs_attempt(const BtrsK& c, double u1, double v, double& k) {
+  const double u = u1 - 0.5;
+  const double us = 0.5 - __builtin_fabs(u);
+  k = floor_((2.0 * c.a / us + c.b) * u + c.c);
+  if (us >= 0.07 && v <= c.vr) return true;
+  if (k < 0.0 || k > c.n) return false;
+  const double lv = flog_stream(v * c.alpha / (c.a / (us * us) + c.b));
+  const double upper = c.hm + (c.n + 1.0) * flog_stream((c.n - c.m + 1.0) / (c.n - k + 1.0)) +
+                       (k + 0.5) * flog_stream(c.r * (c.n - k + 1.0) / (k + 1.0)) - stirling_tail(k) - stirling_tail(c.n - k);
+  return lv <= upper;
+}
+
 // Binomial(n, p) as a double holding an integer.  n must be a non-negative integer value.
 M355_DEV double sample_binomial(RngState& st, double n, double p) {
   if (!(n >= 0.0) || !(p >= 0.0) || !(p <= 1.0)) return kNaN;
@@ -217,10 +274,10 @@ M355_DEV double sample_binomial(RngState& st, double n, double p) {
   if (p == 1.0) return n;
   const bool flip = p > 0.5;
   const double pp = flip ? 1.0 - p : p;
-  const double q = 1.0 - pp;
   double k = 0.0;
   if (n * pp < 10.0) {
     // sequential inversion from one uniform (restarts in the ~1e-16 tail the sum cannot reach)
+    const double q = 1.0 - pp;
     const double r = pp / q;
     for (int it = 0; it < kMaxAttempts; ++it) {
       double u1, u2;
@@ -235,30 +292,12 @@ M355_DEV double sample_binomial(RngState& st, double n, double p) {
       if (u1 <= s || k >= n) break;
     }
   } else {
-    // BTRS (Hoermann 1993, "The generation of binomial random variates")
-    const double spq = fsqrt(n * pp * q);
-    const double b = 1.15 + 2.53 * spq;
-    const double a = -0.0873 + 0.0248 * b + 0.01 * pp;
-    const double c = n * pp + 0.5;
-    const double vr = 0.92 - 4.2 / b;
-    const double r = pp / q;
-    const double alpha = (2.83 + 5.1 / b) * spq;
-    const double m = floor_((n + 1.0) * pp);
-    k = m;
+    const BtrsK c = btrs_setup(n, p);
+    k = c.m;
     for (int it = 0; it < kMaxAttempts; ++it) {
       double u1, v;
       next_pair(st, u1, v);
-      const double u = u1 - 0.5;
-      const double us = 0.5 - __builtin_fabs(u);
-      k = floor_((2.0 * a / us + b) * u + c);
-      if (us >= 0.07 && v <= vr) break;
-      if (k < 0.0 || k > n) continue;
-      const double lv = flog_stream(v * alpha / (a / (us * us) + b));
-      const double upper = (m + 0.5) * flog_stream((m + 1.0) / (r * (n - m + 1.0))) +
-                           (n + 1.0) * flog_stream((n - m + 1.0) / (n - k + 1.0)) +
-                           (k + 0.5) * flog_stream(r * (n - k + 1.0) / (k + 1.0)) + stirling_tail(m) +
-                           stirling_tail(n - m) - stirling_tail(k) - stirling_tail(n - k);
-      if (lv <= upper) break;
+      if (btrs_attempt(c, u1, v, k)) break;
     }
   }
   return flip ? n - k : k;

@@ -44,6 +44,66 @@ __global__ __launch_bounds__(kBlock) void k_rvs_normal_pairs(double* __restrict_
   }
 }
 
+// Rejection samplers with wavefront-level compaction (PTRS Poisson, BTRS binomial; scalar
+// parameters).  A wavefront owns a contiguous chunk of the output.  Every round each lane makes ONE
+// attempt for the element it holds; lanes whose attempt was accepted store the draw and take the next
+// unassigned element of the chunk (rank among the freed lanes from a ballot + mbcnt prefix count),
+// so all 64 lanes keep proposing instead of idling until the slowest lane of a fixed group of 64
+// elements is accepted.  A draw still depends only on (seed, stream, element index, attempt
+// number), never on the lane that computed it: the output is identical to k_rvs.
+template <int D>
+__global__ __launch_bounds__(kBlock) void k_rvs_compact(void* __restrict__ out, int odt, long long n, double p0, double p1,
+                                                        unsigned long long seed, unsigned stream,
+                                                        unsigned long long offset) {
+  const long long wave = (long long)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  const long long nwaves = (long long)gridDim.x * (kBlock / 64);
+  const long long chunk = ((n + nwaves - 1) / nwaves + 63) & ~63ll;
+  const long long w1 = (wave + 1) * chunk < n ? (wave + 1) * chunk : n;
+  long long next = wave * chunk;  // wave-uniform: first unassigned element
+  if (next >= w1) return;
+  PtrsK pk;
+  BtrsK bk;
+  if constexpr (D == M355_POISSON) pk = ptrs_setup(p0);
+  else bk = btrs_setup(p0, p1);
+  long long idx = -1;  // element held by this lane (-1: none)
+  unsigned attempt = 0;
+  for (;;) {
+    // refill the free lanes from the chunk
+    const bool freed = idx < 0;
+    const unsigned long long fm = __ballot(freed);
+    const unsigned below = __builtin_amdgcn_mbcnt_hi((unsigned)(fm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)fm, 0u));
+    if (freed) {
+      const long long cand = next + below;
+      if (cand < w1) {
+        idx = cand;
+        attempt = 0;
+      }
+    }
+    next += __popcll(fm);
+    if (next > w1) next = w1;
+    const bool active = idx >= 0;
+    if (__ballot(active) == 0ull) break;  // chunk exhausted and every lane has stored its draw
+    if (active) {
+      const unsigned long long c = offset + (unsigned long long)idx;
+      const Philox ph = philox4x32_10((unsigned)c, (unsigned)(c >> 32), attempt, stream, (unsigned)seed, (unsigned)(seed >> 32));
+      attempt += 1;
+      const double u1 = u53(ph.c[0], ph.c[1]), v = u53(ph.c[2], ph.c[3]);
+      double k;
+      bool ok;
+      if constexpr (D == M355_POISSON) {
+        ok = ptrs_attempt(pk, u1, v, k);
+      } else {
+        ok = btrs_attempt(bk, u1, v, k);
+        if (bk.flip) k = bk.n - k;
+      }
+      if (ok || attempt >= (unsigned)kMaxAttempts) {
+        store_draw(out, odt, idx, k);
+        idx = -1;
+      }
+    }
+  }
+}
+
 template <int D> int launch_rvs(const GenericOps& ops, void* out, int odt, long long n, unsigned long long seed,
                                 unsigned stream, unsigned long long offset, hipStream_t s) {
   const long long want = (n + kBlock - 1) / kBlock;
@@ -69,6 +129,22 @@ extern "C" int m355_rvs_impl(int dist, int out_dtype, long long n, const m355::G
     // odd tail element
     return launch_rvs<M355_NORMAL>(*ops, static_cast<double*>(out) + (n - 1), out_dtype, 1, seed, stream_id,
                                    offset + (unsigned long long)(n - 1), s);
+  }
+  const bool scalar2 = ops->p[0].ptr == nullptr && ops->p[1].ptr == nullptr;
+  const double q0 = ops->p[0].scalar, q1 = ops->p[1].scalar;
+  const bool ptrs = dist == M355_POISSON && ops->p[0].ptr == nullptr && q0 >= 10.0 && q0 < kInf;
+  const bool btrs = dist == M355_BINOMIAL && scalar2 && q0 >= 0.0 && q0 < kInf && q1 > 0.0 && q1 < 1.0 &&
+                    q0 * (q1 > 0.5 ? 1.0 - q1 : q1) >= 10.0;
+  if ((ptrs || btrs) && n >= 4096) {
+    const long long want = (n + 4 * kBlock - 1) / (4 * kBlock);  // >= 256 elements per wavefront
+    const int blocks = (int)(want > 8192 ? 8192 : want);
+    if (ptrs)
+      hipLaunchKernelGGL((k_rvs_compact<M355_POISSON>), dim3(blocks), dim3(kBlock), 0, s, out, out_dtype, n, q0, 0.0, seed,
+                         stream_id, offset);
+    else
+      hipLaunchKernelGGL((k_rvs_compact<M355_BINOMIAL>), dim3(blocks), dim3(kBlock), 0, s, out, out_dtype, n, q0, q1, seed,
+                         stream_id, offset);
+    return (int)hipGetLastError();
   }
   switch (dist) {
     case M355_NORMAL: return launch_rvs<M355_NORMAL>(*ops, out, out_dtype, n, seed, stream_id, offset, s);
