@@ -27,8 +27,18 @@ using m355::fail;
 // Fixed-order sum of the per-workgroup partials (one workgroup): deterministic total.
 __global__ __launch_bounds__(m355::kBlock) void k_final(const double* __restrict__ partials, int nparts,
                                                           double* __restrict__ out) {
+  // all loads issued before the first add: one memory round trip instead of nparts / 256 of them
+  constexpr int kPer = m355::kMaxReduceBlocks / m355::kBlock;
+  double v[kPer];
+#pragma unroll
+  for (int j = 0; j < kPer; ++j) {
+    const int i = threadIdx.x + j * m355::kBlock;
+    v[j] = i < nparts ? partials[i] : 0.0;
+  }
   double acc = 0.0;
-  for (int i = threadIdx.x; i < nparts; i += m355::kBlock) acc += partials[i];
+#pragma unroll
+  for (int j = 0; j < kPer; ++j) acc += v[j];
+  for (int i = threadIdx.x + kPer * m355::kBlock; i < nparts; i += m355::kBlock) acc += partials[i];
   acc = m355::block_reduce_sum(acc);
   if (threadIdx.x == 0) out[0] = acc;
 }
