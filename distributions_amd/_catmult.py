@@ -15,7 +15,7 @@ from ._lib import F32, F64, FN, I64
 _vp, _i32, _i64, _dbl, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_double, ctypes.c_size_t
 _u64, _u32 = ctypes.c_uint64, ctypes.c_uint32
 _bound = False
-CATEGORICAL_STREAM, MULTINOMIAL_STREAM = 6, 7
+CATEGORICAL_STREAM, MULTINOMIAL_STREAM = 1000, 1001  # Philox stream ids (elementwise families use their dist id)
 
 
 def _bind():

@@ -210,7 +210,7 @@ def sumlogp(dist: str, fn: str, x: Any, *params: Any):
 
 
 # ------------------------------------------------------------------------------------------- rvs
-_STREAM_ID = {"normal": 0, "gamma": 1, "beta": 2, "studentt": 3, "poisson": 4, "binomial": 5}
+_STREAM_ID = DIST  # Philox stream id = distribution id
 
 
 def _seed_of(random_state) -> Tuple[int, int]:

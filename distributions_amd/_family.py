@@ -1,0 +1,38 @@
+"""Builds the reference's module-level function surface (pdf, logpdf, cdf, logcdf, sf, logsf, ppf, isf,
+rvs + the fused sum_logpdf) for one distribution of the elementwise path, with the reference's
+parameter names and order (``_lib.PARAMS``), each function one call into the C-ABI."""
+
+from __future__ import annotations
+
+from ._dispatch import elemwise as _elemwise
+from ._dispatch import rvs as _rvs
+from ._dispatch import sumlogp as _sumlogp
+from ._lib import FN, PARAMS
+
+
+def export(ns: dict, dist: str, cites: dict | None = None) -> None:
+    """Define the functions of `dist` in the module namespace `ns`.  `cites` maps a function name to
+    the reference lines it replaces (goes into the docstring)."""
+    names = PARAMS[dist]
+    sig = ", ".join(names)
+    cites = cites or {}
+    for fn in FN:
+        first = "q" if fn in ("ppf", "isf") else "x"
+        src = (f"def {fn}({first}, {sig}):\n"
+               f"    return _elemwise({dist!r}, {fn!r}, {first}, {sig})\n")
+        loc: dict = {}
+        exec(src, {"_elemwise": _elemwise}, loc)  # noqa: S102 - fixed template, gives real signatures
+        f = loc[fn]
+        f.__doc__ = f"{dist}.py:{cites.get(fn, '?')} of the reference, evaluated by the HIP elementwise kernels."
+        f.__module__ = ns.get("__name__", __name__)
+        ns[fn] = f
+    loc = {}
+    exec(f"def sum_logpdf(x, {sig}):\n    return _sumlogp({dist!r}, 'logpdf', x, {sig})\n", {"_sumlogp": _sumlogp}, loc)  # noqa: S102
+    loc["sum_logpdf"].__doc__ = "sum(logpdf(x, ...)) fused in one pass (the reference spells it pt.sum(logpdf(...)))."
+    ns["sum_logpdf"] = loc["sum_logpdf"]
+    loc = {}
+    exec(f"def rvs({sig}, size=None, random_state=None):\n"
+         f"    return _rvs({dist!r}, ({sig},), size=size, random_state=random_state)\n", {"_rvs": _rvs}, loc)  # noqa: S102
+    loc["rvs"].__doc__ = (f"{dist}.py:{cites.get('rvs', '?')} of the reference; Philox counter-based draws, statistically "
+                          "equivalent to the reference sampler (SURVEY.md quirk Q3).")
+    ns["rvs"] = loc["rvs"]

@@ -13,9 +13,40 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libm355dist.so")
 
 F64, F32, I64 = 0, 1, 2
-DIST = {"normal": 0, "gamma": 1, "beta": 2, "studentt": 3, "poisson": 4, "binomial": 5}
+# distribution ids of include/m355_dist.h (enum m355_dist) and the reference's parameter names, in order
+PARAMS = {
+    "normal": ('mu', 'sigma'),
+    "gamma": ('alpha', 'beta'),
+    "beta": ('alpha', 'beta'),
+    "studentt": ('nu', 'mu', 'sigma'),
+    "poisson": ('mu',),
+    "binomial": ('n', 'p'),
+    "exponential": ('lam',),
+    "lognormal": ('mu', 'sigma'),
+    "halfnormal": ('sigma',),
+    "cauchy": ('alpha', 'beta'),
+    "halfcauchy": ('beta',),
+    "laplace": ('mu', 'b'),
+    "logistic": ('mu', 's'),
+    "gumbel": ('mu', 'beta'),
+    "weibull": ('alpha', 'beta'),
+    "pareto": ('alpha', 'm'),
+    "uniform": ('lower', 'upper'),
+    "triangular": ('lower', 'c', 'upper'),
+    "kumaraswamy": ('a', 'b'),
+    "moyal": ('mu', 'sigma'),
+    "asymmetriclaplace": ('mu', 'b', 'kappa'),
+    "loglogistic": ('alpha', 'beta'),
+    "logitnormal": ('mu', 'sigma'),
+    "inversegamma": ('alpha', 'beta'),
+    "chisquared": ('nu',),
+    "scaledinversechisquared": ('nu', 'tau2'),
+    "halfstudentt": ('nu', 'sigma'),
+    "betascaled": ('alpha', 'beta', 'lower', 'upper'),
+}
+DIST = {name: i for i, name in enumerate(PARAMS)}
+NPARAMS = {name: len(ps) for name, ps in PARAMS.items()}
 FN = {"logpdf": 0, "logcdf": 1, "logsf": 2, "ppf": 3, "pdf": 4, "cdf": 5, "sf": 6, "isf": 7}
-NPARAMS = {"normal": 2, "gamma": 2, "beta": 2, "studentt": 3, "poisson": 1, "binomial": 2}
 
 
 class Operand(ctypes.Structure):

@@ -67,12 +67,10 @@ bool convert(const m355_operand& in, long long n, bool is_param, m355::DevOperan
 
 int nparams_of(int dist) {
   switch (dist) {
-    case M355_NORMAL: return 2;
-    case M355_GAMMA: return 2;
-    case M355_BETA: return 2;
-    case M355_STUDENTT: return 3;
-    case M355_POISSON: return 1;
-    case M355_BINOMIAL: return 2;
+#define M355_NP_CASE(ID, name, np) \
+  case ID: return np;
+    M355_DIST_LIST(M355_NP_CASE)
+#undef M355_NP_CASE
   }
   return -1;
 }
@@ -91,7 +89,7 @@ int build_args(int dist, int fn, int out_dtype, int64_t n, const m355_operand* x
   a.n = n;
   a.nparams = np;
   if (!convert(*x, n, false, a.x, "x")) return M355_ERR_INVALID;
-  for (int q = 0; q < 3; ++q) {
+  for (int q = 0; q < m355::kMaxParams; ++q) {
     a.p[q] = m355::DevOperand{nullptr, 0.0, 1, 1, M355_F64};
     if (q < np && !convert(params[q], n, true, a.p[q], "parameter")) return M355_ERR_INVALID;
   }
@@ -100,12 +98,10 @@ int build_args(int dist, int fn, int out_dtype, int64_t n, const m355_operand* x
 
 int dispatch(int dist, const m355::LaunchArgs& a) {
   switch (dist) {
-    case M355_NORMAL: return m355_launch_normal(a);
-    case M355_GAMMA: return m355_launch_gamma(a);
-    case M355_BETA: return m355_launch_beta(a);
-    case M355_STUDENTT: return m355_launch_studentt(a);
-    case M355_POISSON: return m355_launch_poisson(a);
-    case M355_BINOMIAL: return m355_launch_binomial(a);
+#define M355_LAUNCH_CASE(ID, name, np) \
+  case ID: return m355_launch_##name(a);
+    M355_DIST_LIST(M355_LAUNCH_CASE)
+#undef M355_LAUNCH_CASE
   }
   return -1000;
 }
@@ -195,7 +191,7 @@ int m355_rvs(int dist, int out_dtype, int64_t n, int nparams, const m355_operand
   if (out == nullptr) return fail(M355_ERR_INVALID, "out must not be NULL");
   m355::GenericOps ops;
   ops.x = m355::DevOperand{nullptr, 0.0, 1, 1, M355_F64};
-  for (int q = 0; q < 3; ++q) {
+  for (int q = 0; q < m355::kMaxParams; ++q) {
     ops.p[q] = m355::DevOperand{nullptr, 0.0, 1, 1, M355_F64};
     if (q < np && !convert(params[q], n, true, ops.p[q], "parameter")) return M355_ERR_INVALID;
   }

@@ -358,7 +358,7 @@ template <> struct Dist<M355_BINOMIAL> {
 // Which (dist, fn) pairs exist on the path: all eight functions of all six distributions.
 constexpr bool supported(int dist, int fn) {
   if (fn < 0 || fn > M355_ISF) return false;
-  return dist >= M355_NORMAL && dist <= M355_BINOMIAL;
+  return dist >= M355_NORMAL && dist < M355_DIST_COUNT;
 }
 
 }  // namespace m355

@@ -20,7 +20,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
-#include "m355_dists.h"
+#include "m355_dist_list.h"
+#include "m355_dists2.h"
 
 namespace m355 {
 
@@ -31,13 +32,15 @@ struct DevOperand {
   int dtype;
 };
 
+constexpr int kMaxParams = 4;  // betascaled has four
+
 struct LaunchArgs {
   int fn;
   int out_dtype;
   long long n;
   DevOperand x;
   int nparams;
-  DevOperand p[3];
+  DevOperand p[kMaxParams];
   void* out;         // elementwise result (unused with partials)
   double* partials;  // non-null: reduce, one double per workgroup
   int* nblocks_out;  // receives the number of partials written
@@ -148,8 +151,8 @@ __global__ __launch_bounds__(kBlock) void k_scalar(const void* __restrict__ x, i
 }
 
 struct PeriodicParams {
-  const double* ptr[3];  // NULL: scalar
-  double scalar[3];
+  const double* ptr[kMaxParams];  // NULL: scalar
+  double scalar[kMaxParams];
 };
 
 template <int D, int FN, bool REDUCE, bool F64IO>
@@ -162,9 +165,9 @@ __global__ __launch_bounds__(kBlock) void k_periodic(const void* __restrict__ x,
   constexpr int NK = sizeof(K) / sizeof(double);
   extern __shared__ double lds[];  // [NK][P]
   for (unsigned j = threadIdx.x; j < P; j += kBlock) {
-    double pp[3];
+    double pp[kMaxParams];
 #pragma unroll
-    for (int q = 0; q < 3; ++q) pp[q] = (q < DD::NP && pa.ptr[q]) ? pa.ptr[q][j] : pa.scalar[q];
+    for (int q = 0; q < kMaxParams; ++q) pp[q] = (q < DD::NP && pa.ptr[q]) ? pa.ptr[q][j] : pa.scalar[q];
     const K k = DD::derive(pp);
     const double* kd = reinterpret_cast<const double*>(&k);
 #pragma unroll
@@ -221,7 +224,7 @@ __global__ __launch_bounds__(kBlock) void k_periodic(const void* __restrict__ x,
 
 struct GenericOps {
   DevOperand x;
-  DevOperand p[3];
+  DevOperand p[kMaxParams];
 };
 
 M355_DEV double fetch_operand(const DevOperand& o, unsigned long long i, bool small) {
@@ -247,7 +250,7 @@ __global__ __launch_bounds__(kBlock) void k_generic(GenericOps ops, void* __rest
   double acc = 0.0;
   for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < n; i += (long long)gridDim.x * kBlock) {
     const double xv = fetch_operand(ops.x, (unsigned long long)i, small);
-    double pp[3] = {0.0, 0.0, 0.0};
+    double pp[kMaxParams] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int q = 0; q < DD::NP; ++q) pp[q] = fetch_operand(ops.p[q], (unsigned long long)i, small);
     const double r = DD::template eval<FN>(xv, DD::derive(pp));
@@ -296,7 +299,7 @@ template <int D, int FN, bool REDUCE> int launch_fn(const LaunchArgs& a) {
   if (REDUCE && a.nblocks_out) *a.nblocks_out = blocks;
   if (vec_ok && all_scalar) {
     // parameter-only constants once, on the host; they reach the kernel as arguments (SGPRs)
-    const double pp[3] = {a.p[0].scalar, a.p[1].scalar, a.p[2].scalar};
+    const double pp[kMaxParams] = {a.p[0].scalar, a.p[1].scalar, a.p[2].scalar, a.p[3].scalar};
     const typename DD::K k = DD::derive(pp);
     if (f64io) {
       if constexpr (kFastIO)
@@ -308,7 +311,7 @@ template <int D, int FN, bool REDUCE> int launch_fn(const LaunchArgs& a) {
     }
   } else if (vec_ok && periodic_ok) {
     PeriodicParams pa;
-    for (int q = 0; q < 3; ++q) {
+    for (int q = 0; q < kMaxParams; ++q) {
       pa.ptr[q] = (q < DD::NP) ? static_cast<const double*>(a.p[q].ptr) : nullptr;
       pa.scalar[q] = a.p[q].scalar;
     }
@@ -324,7 +327,7 @@ template <int D, int FN, bool REDUCE> int launch_fn(const LaunchArgs& a) {
   } else {
     GenericOps ops;
     ops.x = a.x;
-    for (int q = 0; q < 3; ++q) ops.p[q] = a.p[q];
+    for (int q = 0; q < kMaxParams; ++q) ops.p[q] = a.p[q];
     hipLaunchKernelGGL((k_generic<D, FN, REDUCE>), dim3(blocks), dim3(kBlock), 0, a.stream, ops, a.out,
                        a.out_dtype, n, a.partials);
   }
@@ -355,10 +358,11 @@ template <int D, bool REDUCE> int launch_dist(const LaunchArgs& a) {
 
 }  // namespace m355
 
-// One translation unit per distribution defines these (keeps hipcc compile times parallel).
-int m355_launch_normal(const m355::LaunchArgs& a);
-int m355_launch_gamma(const m355::LaunchArgs& a);
-int m355_launch_beta(const m355::LaunchArgs& a);
-int m355_launch_studentt(const m355::LaunchArgs& a);
-int m355_launch_poisson(const m355::LaunchArgs& a);
-int m355_launch_binomial(const m355::LaunchArgs& a);
+// One translation unit per distribution defines its launcher (keeps hipcc compile times parallel).
+#define M355_DECLARE_LAUNCH(ID, name, np) int m355_launch_##name(const m355::LaunchArgs& a);
+M355_DIST_LIST(M355_DECLARE_LAUNCH)
+#undef M355_DECLARE_LAUNCH
+#define M355_DEFINE_LAUNCH(ID, name)                                                                  \
+  int m355_launch_##name(const m355::LaunchArgs& a) {                                                  \
+    return a.partials ? m355::launch_dist<ID, true>(a) : m355::launch_dist<ID, false>(a);              \
+  }

@@ -334,8 +334,57 @@ template <int D> M355_DEV double sample_one(unsigned long long idx, unsigned lon
     return p[1] + p[2] * z0 * fsqrt(0.5 * p[0] / g);
   } else if constexpr (D == M355_POISSON) {  // poisson.py:66-67
     return sample_poisson(st, p[0]);
-  } else {  // binomial.py:62-63
+  } else if constexpr (D == M355_BINOMIAL) {  // binomial.py:62-63
     return sample_binomial(st, p[0], p[1]);
+  } else if constexpr (D == M355_INVERSEGAMMA) {  // inversegamma.py:69-70: 1 / Gamma(alpha, rate beta)
+    return p[1] / sample_std_gamma(st, p[0]);
+  } else if constexpr (D == M355_CHISQUARED) {  // chisquared.py:59-60
+    return 2.0 * sample_std_gamma(st, 0.5 * p[0]);
+  } else if constexpr (D == M355_SCALEDINVERSECHISQUARED) {  // scaledinversechisquared.py:64-65
+    return (p[0] * p[1]) / (2.0 * sample_std_gamma(st, 0.5 * p[0]));
+  } else if constexpr (D == M355_BETASCALED) {  // betascaled.py:107-109
+    const double ga = sample_std_gamma(st, p[0]);
+    const double gb = sample_std_gamma(st, p[1]);
+    return ga / (ga + gb) * (p[3] - p[2]) + p[2];
+  } else {
+    // samplers driven by one normal pair and / or one uniform pair
+    double u1, u2, z0, z1;
+    next_pair(st, u1, u2);
+    if constexpr (D == M355_LOGNORMAL || D == M355_HALFNORMAL || D == M355_LOGITNORMAL || D == M355_MOYAL ||
+                  D == M355_HALFSTUDENTT)
+      normal_pair(u1, u2, z0, z1);
+    if constexpr (D == M355_EXPONENTIAL) return -flog(u1) / p[0];                          // exponential.py:62-63
+    if constexpr (D == M355_LOGNORMAL) return exp_(p[0] + p[1] * z0);                      // lognormal.py:68-69
+    if constexpr (D == M355_HALFNORMAL) return __builtin_fabs(p[0] * z0);                  // halfnormal.py:62-63
+    if constexpr (D == M355_CAUCHY) return p[0] + p[1] * tan_(kPi * (u1 - 0.5));           // cauchy.py:62-63
+    if constexpr (D == M355_HALFCAUCHY) return p[0] * tan_(kPi / 2.0 * u1);                // halfcauchy.py:69-71
+    if constexpr (D == M355_LAPLACE)                                                      // laplace.py:68-69
+      return (u1 < 0.5) ? p[0] + p[1] * flog(2.0 * u1) : p[0] - p[1] * flog(2.0 * (1.0 - u1));
+    if constexpr (D == M355_LOGISTIC) return p[0] + p[1] * flog(u1 / (1.0 - u1));          // logistic.py:58-59
+    if constexpr (D == M355_GUMBEL) return p[0] - p[1] * flog(-flog(u1));                  // gumbel.py:61-62
+    if constexpr (D == M355_WEIBULL) return p[1] * pow_(-flog(u1), 1.0 / p[0]);            // weibull.py:64-65
+    if constexpr (D == M355_PARETO) return p[1] / pow_(u1, 1.0 / p[0]);                    // pareto.py:63-65
+    if constexpr (D == M355_UNIFORM) return p[0] + u1 * (p[1] - p[0]);                     // uniform.py:66-67
+    if constexpr (D == M355_TRIANGULAR) {                                                 // triangular.py:85-87 (own ppf)
+      const double w = p[2] - p[0];
+      return (u1 < (p[1] - p[0]) / w) ? p[0] + sqrt_(w * (p[1] - p[0]) * u1) : p[2] - sqrt_(w * (p[2] - p[1]) * (1.0 - u1));
+    }
+    if constexpr (D == M355_KUMARASWAMY)                                                  // kumaraswamy.py:69-71 (own ppf)
+      return pow_(1.0 - pow_(1.0 - u1, 1.0 / p[1]), 1.0 / p[0]);
+    if constexpr (D == M355_MOYAL) return p[0] - p[1] * flog(z0 * z0);                     // moyal.py:66-68: ppf(U) = mu - sigma log Z^2
+    if constexpr (D == M355_ASYMMETRICLAPLACE) {                                          // asymmetriclaplace.py:91-96
+      const double r = -p[2] + u1 * (1.0 / p[2] + p[2]);  // uniform(-kappa, 1/kappa)
+      const double sgn = (r > 0.0) ? 1.0 : ((r < 0.0) ? -1.0 : 0.0);
+      const double ks = pow_(p[2], sgn);
+      return p[0] - (1.0 / (1.0 / p[1] * sgn * ks)) * flog(1.0 - r * sgn * ks);
+    }
+    if constexpr (D == M355_LOGLOGISTIC) return p[0] * pow_(u1 / (1.0 - u1), 1.0 / p[1]);  // loglogistic.py:107-109
+    if constexpr (D == M355_LOGITNORMAL) return sigmoid_(p[0] + p[1] * z0);                // logitnormal.py:191-192
+    if constexpr (D == M355_HALFSTUDENTT) {                                               // halfstudentt.py:117-119
+      const double g = sample_std_gamma(st, 0.5 * p[0]);
+      return __builtin_fabs(z0 * fsqrt(0.5 * p[0] / g) * p[1]);
+    }
+    return kNaN;
   }
 }
 

@@ -20,7 +20,7 @@ __global__ __launch_bounds__(kBlock) void k_rvs(GenericOps ops, void* __restrict
                                                 unsigned long long offset) {
   const bool small = n <= 0xffffffffll;
   for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < n; i += (long long)gridDim.x * kBlock) {
-    double pp[3] = {0.0, 0.0, 0.0};
+    double pp[kMaxParams] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int q = 0; q < Dist<D>::NP; ++q) pp[q] = fetch_operand(ops.p[q], (unsigned long long)i, small);
     store_draw(out, odt, i, sample_one<D>(offset + (unsigned long long)i, seed, stream, pp));
@@ -147,12 +147,10 @@ extern "C" int m355_rvs_impl(int dist, int out_dtype, long long n, const m355::G
     return (int)hipGetLastError();
   }
   switch (dist) {
-    case M355_NORMAL: return launch_rvs<M355_NORMAL>(*ops, out, out_dtype, n, seed, stream_id, offset, s);
-    case M355_GAMMA: return launch_rvs<M355_GAMMA>(*ops, out, out_dtype, n, seed, stream_id, offset, s);
-    case M355_BETA: return launch_rvs<M355_BETA>(*ops, out, out_dtype, n, seed, stream_id, offset, s);
-    case M355_STUDENTT: return launch_rvs<M355_STUDENTT>(*ops, out, out_dtype, n, seed, stream_id, offset, s);
-    case M355_POISSON: return launch_rvs<M355_POISSON>(*ops, out, out_dtype, n, seed, stream_id, offset, s);
-    case M355_BINOMIAL: return launch_rvs<M355_BINOMIAL>(*ops, out, out_dtype, n, seed, stream_id, offset, s);
+#define M355_RVS_CASE(ID, name, np) \
+  case ID: return launch_rvs<ID>(*ops, out, out_dtype, n, seed, stream_id, offset, s);
+    M355_DIST_LIST(M355_RVS_CASE)
+#undef M355_RVS_CASE
   }
   return -1000;
 }

@@ -25,6 +25,9 @@ M355_DEV double erfcx_(double x) { return ::erfcx(x); }
 M355_DEV double erfinv_(double x) { return ::erfinv(x); }
 M355_DEV double sqrt_(double x) { return __builtin_sqrt(x); }
 M355_DEV double floor_(double x) { return __builtin_floor(x); }
+M355_DEV double pow_(double x, double y) { return ::pow(x, y); }
+M355_DEV double atan_(double x) { return ::atan(x); }
+M355_DEV double tan_(double x) { return ::tan(x); }
 #else
 M355_DEV double exp_(double x) { return std::exp(x); }
 M355_DEV double expm1_(double x) { return std::expm1(x); }
@@ -35,7 +38,24 @@ M355_DEV double erfcx_(double x) { return kNaN; }   // device libm only; not hos
 M355_DEV double erfinv_(double x) { return kNaN; }  // device libm only; not host-tested
 M355_DEV double sqrt_(double x) { return std::sqrt(x); }
 M355_DEV double floor_(double x) { return std::floor(x); }
+M355_DEV double pow_(double x, double y) { return std::pow(x, y); }
+M355_DEV double atan_(double x) { return std::atan(x); }
+M355_DEV double tan_(double x) { return std::tan(x); }
 #endif
+
+// pt.log1mexp: log(1 - exp(x)) for x <= 0.
+M355_DEV double log1mexp_(double x) {
+  return (x < -0.69314718055994530942) ? flog1p(-exp_(x)) : flog(-expm1_(x));
+}
+// pt.log1pexp (softplus), PyTensor's piecewise form.
+M355_DEV double log1pexp_(double x) {
+  if (x < -37.0) return exp_(x);
+  if (x < 18.0) return flog1p(exp_(x));
+  if (x < 33.3) return x + exp_(-x);
+  return x;
+}
+// pt.sigmoid
+M355_DEV double sigmoid_(double x) { return 1.0 / (1.0 + exp_(-x)); }
 
 // ------------------------------------------------------------------------------------------------
 // log(1+u) - u.  Series form 2*atanh(s) - u with s = u/(2+u) while |s| stays inside the range of

@@ -46,12 +46,35 @@ enum m355_dtype { M355_F64 = 0, M355_F32 = 1, M355_I64 = 2 };
 
 /* distribution ids: the reference module each one replaces */
 enum m355_dist {
-  M355_NORMAL = 0,   /* normal.py   */
-  M355_GAMMA = 1,    /* gamma.py    */
-  M355_BETA = 2,     /* beta.py     */
-  M355_STUDENTT = 3, /* studentt.py */
-  M355_POISSON = 4,  /* poisson.py  */
-  M355_BINOMIAL = 5  /* binomial.py */
+  M355_NORMAL = 0,                    /* normal.py */
+  M355_GAMMA = 1,                     /* gamma.py */
+  M355_BETA = 2,                      /* beta.py */
+  M355_STUDENTT = 3,                  /* studentt.py */
+  M355_POISSON = 4,                   /* poisson.py */
+  M355_BINOMIAL = 5,                  /* binomial.py */
+  M355_EXPONENTIAL = 6,               /* exponential.py */
+  M355_LOGNORMAL = 7,                 /* lognormal.py */
+  M355_HALFNORMAL = 8,                /* halfnormal.py */
+  M355_CAUCHY = 9,                    /* cauchy.py */
+  M355_HALFCAUCHY = 10,                /* halfcauchy.py */
+  M355_LAPLACE = 11,                   /* laplace.py */
+  M355_LOGISTIC = 12,                  /* logistic.py */
+  M355_GUMBEL = 13,                    /* gumbel.py */
+  M355_WEIBULL = 14,                   /* weibull.py */
+  M355_PARETO = 15,                    /* pareto.py */
+  M355_UNIFORM = 16,                   /* uniform.py */
+  M355_TRIANGULAR = 17,                /* triangular.py */
+  M355_KUMARASWAMY = 18,               /* kumaraswamy.py */
+  M355_MOYAL = 19,                     /* moyal.py */
+  M355_ASYMMETRICLAPLACE = 20,         /* asymmetriclaplace.py */
+  M355_LOGLOGISTIC = 21,               /* loglogistic.py */
+  M355_LOGITNORMAL = 22,               /* logitnormal.py */
+  M355_INVERSEGAMMA = 23,              /* inversegamma.py */
+  M355_CHISQUARED = 24,                /* chisquared.py */
+  M355_SCALEDINVERSECHISQUARED = 25,   /* scaledinversechisquared.py */
+  M355_HALFSTUDENTT = 26,              /* halfstudentt.py */
+  M355_BETASCALED = 27,                /* betascaled.py */
+  M355_DIST_COUNT = 28
 };
 
 /* function ids: the reference function of that module */
@@ -89,7 +112,9 @@ int m355_device_count(void);
  * out[i] = fn_dist(x[i], params...) for i in [0, n): replaces the fused Elemwise loop PyTensor
  * compiles for <dist>.<fn>(x, *params) (functions cited at enum m355_fn).  `out_dtype` is
  * M355_F64 or M355_F32.  Parameter order is the reference's (normal: mu, sigma; gamma: alpha,
- * beta; beta: alpha, beta; studentt: nu, mu, sigma; poisson: mu; binomial: n, p).
+ * beta; beta: alpha, beta; studentt: nu, mu, sigma; poisson: mu; binomial: n, p; the closed-form
+ * and re-parameterised families of SURVEY.md 8(f) rank 1 likewise, e.g. weibull: alpha, beta;
+ * triangular: lower, c, upper; betascaled: alpha, beta, lower, upper -- at most four parameters).
  */
 int m355_elemwise(int dist, int fn, int out_dtype, int64_t n, const m355_operand* x, int nparams,
                   const m355_operand* params, void* out, void* stream);

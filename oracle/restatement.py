@@ -657,3 +657,8 @@ TABLE = {
     for name, obj in list(globals().items())
     if callable(obj) and "_" in name and not name.startswith("_")
 }
+
+# closed-form / re-parameterised families: same table, separate file
+from . import restatement_families as _families  # noqa: E402
+
+TABLE.update(_families.FAMILY_TABLE)

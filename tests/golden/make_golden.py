@@ -16,14 +16,8 @@ sys.path.insert(0, ROOT)
 from oracle import restatement as R  # noqa: E402
 from tests import harness as H  # noqa: E402
 
-FNS = {
-    "normal": ["logpdf", "logcdf", "logsf", "pdf", "cdf", "sf", "ppf", "isf"],
-    "gamma": ["logpdf", "logcdf", "logsf", "pdf", "cdf", "sf", "ppf", "isf"],
-    "beta": ["logpdf", "logcdf", "logsf", "pdf", "cdf", "sf", "ppf", "isf"],
-    "studentt": ["logpdf", "logcdf", "logsf", "pdf", "cdf", "sf", "ppf", "isf"],
-    "poisson": ["logpdf", "logcdf", "logsf", "pdf", "cdf", "sf", "ppf", "isf"],
-    "binomial": ["logpdf", "logcdf", "logsf", "pdf", "cdf", "sf", "ppf", "isf"],
-}
+ALL_FNS = ["logpdf", "logcdf", "logsf", "pdf", "cdf", "sf", "ppf", "isf"]
+FNS = {g[0]: ALL_FNS for g in H.grids()}
 
 
 def main():

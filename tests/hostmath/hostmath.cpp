@@ -2,7 +2,8 @@
 // continued fractions and root finders of csrc/m355_special.h be checked against SciPy while no
 // GPU is attached.  The hardware seeds (v_rcp_f64, v_frexp_*) and the device libm (lgamma, exp,
 // erfc) are replaced by host equivalents, so this is NOT the parity test: parity is tests -m gpu.
-#include "../../distributions_amd/csrc/m355_dists.h"
+#include "../../distributions_amd/csrc/m355_dist_list.h"
+#include "../../distributions_amd/csrc/m355_dists2.h"
 
 using namespace m355;
 
@@ -29,12 +30,10 @@ static int by_fn(int fn, long n, const double* x, const double* p, double* out) 
 
 extern "C" int hm_eval(int dist, int fn, long n, const double* x, const double* p, double* out) {
   switch (dist) {
-    case M355_NORMAL: return by_fn<M355_NORMAL>(fn, n, x, p, out);
-    case M355_GAMMA: return by_fn<M355_GAMMA>(fn, n, x, p, out);
-    case M355_BETA: return by_fn<M355_BETA>(fn, n, x, p, out);
-    case M355_STUDENTT: return by_fn<M355_STUDENTT>(fn, n, x, p, out);
-    case M355_POISSON: return by_fn<M355_POISSON>(fn, n, x, p, out);
-    case M355_BINOMIAL: return by_fn<M355_BINOMIAL>(fn, n, x, p, out);
+#define HM_CASE(ID, name, np) \
+  case ID: return by_fn<ID>(fn, n, x, p, out);
+    M355_DIST_LIST(HM_CASE)
+#undef HM_CASE
   }
   return -1;
 }

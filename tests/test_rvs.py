@@ -197,3 +197,55 @@ def test_gpu_compaction_equals_per_lane_loop(gpu, name, params):
     h = 123_456
     c = np.concatenate([m.rvs(*params, size=h, random_state=(11, 0)), m.rvs(*params, size=n - h, random_state=(11, h))])
     assert np.array_equal(a, c)
+
+
+FAMILY_RVS = [
+    ("exponential", (0.27,), lambda: stats.expon(scale=1 / 0.27)),
+    ("lognormal", (2.0, 0.5), lambda: stats.lognorm(s=0.5, scale=np.exp(2.0))),
+    ("halfnormal", (3.5,), lambda: stats.halfnorm(scale=3.5)),
+    ("cauchy", (-5.0, 0.5), lambda: stats.cauchy(loc=-5.0, scale=0.5)),
+    ("halfcauchy", (3.5,), lambda: stats.halfcauchy(scale=3.5)),
+    ("laplace", (10.0, 2.0), lambda: stats.laplace(loc=10.0, scale=2.0)),
+    ("logistic", (2.5, 4.0), lambda: stats.logistic(loc=2.5, scale=4.0)),
+    ("gumbel", (2.5, 3.5), lambda: stats.gumbel_r(loc=2.5, scale=3.5)),
+    ("weibull", (2.0, 5.0), lambda: stats.weibull_min(c=2.0, scale=5.0)),
+    ("pareto", (2.5, 2.0), lambda: stats.pareto(b=2.5, scale=2.0)),
+    ("uniform", (-5.0, 5.0), lambda: stats.uniform(loc=-5.0, scale=10.0)),
+    ("triangular", (0.0, 0.1, 1.0), lambda: stats.triang(c=0.1, loc=0.0, scale=1.0)),
+    ("kumaraswamy", (1.00000001, 5.0), lambda: stats.beta(a=1.00000001, b=5.0)),
+    ("moyal", (-5.0, 0.5), lambda: stats.moyal(loc=-5.0, scale=0.5)),
+    ("asymmetriclaplace", (-1.0, 2.0, 2.0), lambda: stats.laplace_asymmetric(kappa=2.0, loc=-1.0, scale=2.0)),
+    ("loglogistic", (2.0, 3.0), lambda: stats.fisk(c=3.0, scale=2.0)),
+    ("inversegamma", (5.0, 2.0), lambda: stats.invgamma(a=5.0, scale=2.0)),
+    ("chisquared", (5.0,), lambda: stats.chi2(df=5.0)),
+    ("scaledinversechisquared", (10.0, 2.0), lambda: stats.invgamma(a=5.0, scale=10.0)),
+    ("halfstudentt", (1.0, 3.5), lambda: stats.halfcauchy(scale=3.5)),
+    ("betascaled", (2.0, 5.0, -1.0, 3.0), lambda: stats.beta(a=2.0, b=5.0, loc=-1.0, scale=4.0)),
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name, params, make", FAMILY_RVS, ids=[f[0] for f in FAMILY_RVS])
+def test_gpu_rvs_families(gpu, name, params, make):
+    """rvs of the closed-form / re-parameterised families: KS against the SciPy distribution the
+    reference's own test compares with (p > 1e-3), determinism and partition invariance."""
+    import importlib
+
+    m = importlib.import_module(f"distributions_amd.{name}")
+    n = 200_000
+    x = m.rvs(*params, size=n, random_state=21)
+    assert x.shape == (n,) and x.dtype == np.float64 and np.all(np.isfinite(x))
+    assert stats.kstest(x, make().cdf).pvalue > 1e-3
+    assert np.array_equal(x, m.rvs(*params, size=n, random_state=21))
+    h = 77_777
+    assert np.array_equal(x, np.concatenate([m.rvs(*params, size=h, random_state=(21, 0)),
+                                             m.rvs(*params, size=n - h, random_state=(21, h))]))
+
+
+@pytest.mark.gpu
+def test_gpu_rvs_logitnormal(gpu):
+    from distributions_amd import logitnormal
+
+    x = logitnormal.rvs(-1.0, 1.0, size=200_000, random_state=5)
+    z = np.log(x) - np.log1p(-x)
+    assert stats.kstest(z, stats.norm(-1.0, 1.0).cdf).pvalue > 1e-3
