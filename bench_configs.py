@@ -119,6 +119,35 @@ def config4(torch, n):
                       "note": "whole call: Cholesky + solve + epilogue + output allocation"}), flush=True)
 
 
+def config6(torch, n):
+    """Closed-form / re-parameterised families: logpdf, logcdf and ppf on n fp64
+    points drawn from each distribution's own rvs kernel, scalar parameters (16 B/element)."""
+    from distributions_amd import _dispatch, raw
+    from distributions_amd._lib import PARAMS
+
+    cases = {"exponential": (0.27,), "lognormal": (2.0, 0.5), "halfnormal": (3.5,), "cauchy": (-5.0, 0.5), "halfcauchy": (3.5,),
+             "laplace": (10.0, 2.0), "logistic": (2.5, 4.0), "gumbel": (2.5, 3.5), "weibull": (2.0, 5.0), "pareto": (2.5, 2.0),
+             "uniform": (-5.0, 5.0), "triangular": (0.0, 0.1, 1.0), "kumaraswamy": (2.0, 3.0), "moyal": (-5.0, 0.5),
+             "asymmetriclaplace": (-1.0, 2.0, 2.0), "loglogistic": (2.0, 3.0), "logitnormal": (-1.0, 1.0),
+             "inversegamma": (5.0, 2.0), "chisquared": (5.0,), "scaledinversechisquared": (10.0, 2.0),
+             "halfstudentt": (5.0, 2.0), "betascaled": (2.0, 5.0, -1.0, 3.0)}
+    dev = torch.device("cuda", 0)
+    out = torch.empty(n, dtype=torch.float64, device=dev)
+    g = torch.Generator(device=dev).manual_seed(9)
+    q = torch.rand(n, dtype=torch.float64, device=dev, generator=g).clamp_(1e-12, 1 - 1e-12)
+    for name, p in cases.items():
+        assert len(p) == len(PARAMS[name])
+        x = _dispatch.rvs(name, p, size=n, random_state=3, as_torch=True)
+        row = {"config": 6, "dist": name, "n": n}
+        for fn in ("logpdf", "logcdf", "ppf"):
+            src = q if fn == "ppf" else x
+            ms = timed(torch, lambda: raw.elemwise_into(name, fn, src, p, out), reps=3)
+            row[f"{fn}_ms"] = round(ms, 4)
+            row[f"{fn}_GB_per_s"] = round(16.0 * n / (ms * 1e-3) / 1e9, 1)
+        print(json.dumps(row), flush=True)
+        del x
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--config", default="all")
@@ -133,6 +162,8 @@ def main():
         config3(torch, args.n or 1_000_000_000)
     if args.config in ("4", "all"):
         config4(torch, args.n or 100_000)
+    if args.config in ("6", "all"):
+        config6(torch, args.n or 100_000_000)
 
 
 if __name__ == "__main__":

@@ -25,7 +25,14 @@ M355_DEV double erfcx_(double x) { return ::erfcx(x); }
 M355_DEV double erfinv_(double x) { return ::erfinv(x); }
 M355_DEV double sqrt_(double x) { return __builtin_sqrt(x); }
 M355_DEV double floor_(double x) { return __builtin_floor(x); }
-M355_DEV double pow_(double x, double y) { return ::pow(x, y); }
+// x**y: exp(y log x) on the common path (0 < x < inf, normal): relative error |y ln x| * 3e-16, i.e.
+// <= 2e-13 even next to overflow and ~1e-15 typically, at a third of the cost of ocml's correctly
+// rounded pow; every special case (zero, negative, inf, NaN, subnormal base) goes to ocml.
+M355_DEV double pow_(double x, double y) {
+  const unsigned hx = (unsigned)(__builtin_bit_cast(unsigned long long, x) >> 32);
+  if ((hx - 0x00100000u) < 0x7fe00000u) return ::exp(y * flog_pos(x));
+  return ::pow(x, y);
+}
 M355_DEV double atan_(double x) { return ::atan(x); }
 M355_DEV double tan_(double x) { return ::tan(x); }
 #else
