@@ -246,7 +246,7 @@ def rvs(dist: str, params: Sequence[Any], size=None, random_state=None, as_torch
             raise ValueError(f"parameters of shape {pshape} do not broadcast to size {shape}")
     n = prod(shape)
     seed, offset = _seed_of(random_state)
-    discrete = dist in ("poisson", "binomial")
+    discrete = dist in _lib.DISCRETE
     device = _device_of(params, torch)
     pl = Plan(shape, n, False, [OperandPlan("scalar")] + [classify(_shape_of(a), shape) for a in params])
     with torch.cuda.device(device):

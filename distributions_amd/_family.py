@@ -18,6 +18,8 @@ def export(ns: dict, dist: str, cites: dict | None = None) -> None:
     cites = cites or {}
     for fn in FN:
         first = "q" if fn in ("ppf", "isf") else "x"
+        if first in names:  # discreteweibull has a parameter q: the reference writes ppf(p, q, beta), isf(x, q, beta)
+            first = "p" if fn == "ppf" else "x"
         src = (f"def {fn}({first}, {sig}):\n"
                f"    return _elemwise({dist!r}, {fn!r}, {first}, {sig})\n")
         loc: dict = {}

@@ -43,9 +43,21 @@ PARAMS = {
     "scaledinversechisquared": ('nu', 'tau2'),
     "halfstudentt": ('nu', 'sigma'),
     "betascaled": ('alpha', 'beta', 'lower', 'upper'),
+    "bernoulli": ('p',),
+    "geometric": ('p',),
+    "discreteuniform": ('lower', 'upper'),
+    "discreteweibull": ('q', 'beta'),
+    "negativebinomial": ('n', 'p'),
+    "betabinomial": ('n', 'alpha', 'beta'),
+    "hypergeometric": ('N', 'k', 'n'),
+    "zi_poisson": ('psi', 'mu'),
+    "zi_binomial": ('psi', 'n', 'p'),
+    "zi_negativebinomial": ('psi', 'n', 'p'),
 }
 DIST = {name: i for i, name in enumerate(PARAMS)}
 NPARAMS = {name: len(ps) for name, ps in PARAMS.items()}
+DISCRETE = ("poisson", "binomial", "bernoulli", "geometric", "discreteuniform", "discreteweibull", "negativebinomial",
+            "betabinomial", "hypergeometric", "zi_poisson", "zi_binomial", "zi_negativebinomial")  # rvs returns int64
 FN = {"logpdf": 0, "logcdf": 1, "logsf": 2, "ppf": 3, "pdf": 4, "cdf": 5, "sf": 6, "isf": 7}
 
 

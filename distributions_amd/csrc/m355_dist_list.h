@@ -29,4 +29,14 @@
   X(M355_CHISQUARED, chisquared, 1) \
   X(M355_SCALEDINVERSECHISQUARED, scaledinversechisquared, 2) \
   X(M355_HALFSTUDENTT, halfstudentt, 2) \
-  X(M355_BETASCALED, betascaled, 4)
+  X(M355_BETASCALED, betascaled, 4) \
+  X(M355_BERNOULLI, bernoulli, 1) \
+  X(M355_GEOMETRIC, geometric, 1) \
+  X(M355_DISCRETEUNIFORM, discreteuniform, 2) \
+  X(M355_DISCRETEWEIBULL, discreteweibull, 2) \
+  X(M355_NEGATIVEBINOMIAL, negativebinomial, 2) \
+  X(M355_BETABINOMIAL, betabinomial, 3) \
+  X(M355_HYPERGEOMETRIC, hypergeometric, 3) \
+  X(M355_ZI_POISSON, zi_poisson, 2) \
+  X(M355_ZI_BINOMIAL, zi_binomial, 3) \
+  X(M355_ZI_NEGATIVEBINOMIAL, zi_negativebinomial, 3)

@@ -21,7 +21,7 @@
 #include <hip/hip_runtime.h>
 
 #include "m355_dist_list.h"
-#include "m355_dists2.h"
+#include "m355_dists3.h"
 
 namespace m355 {
 

@@ -336,6 +336,56 @@ template <int D> M355_DEV double sample_one(unsigned long long idx, unsigned lon
     return sample_poisson(st, p[0]);
   } else if constexpr (D == M355_BINOMIAL) {  // binomial.py:62-63
     return sample_binomial(st, p[0], p[1]);
+  } else if constexpr (D == M355_BERNOULLI) {  // bernoulli.py:41-42: binomial(1, p)
+    double u1, u2;
+    next_pair(st, u1, u2);
+    return (u1 < p[0]) ? 1.0 : 0.0;
+  } else if constexpr (D == M355_GEOMETRIC) {  // geometric.py:63-64: inversion, support {1, 2, ...}
+    double u1, u2;
+    next_pair(st, u1, u2);
+    const double g = __builtin_ceil(flog(u1) / flog1p(-p[0]));
+    return g < 1.0 ? 1.0 : g;
+  } else if constexpr (D == M355_DISCRETEUNIFORM) {  // discreteuniform.py:64-65: integers(lower, upper + 1)
+    double u1, u2;
+    next_pair(st, u1, u2);
+    const double n = p[1] - p[0] + 1.0;
+    const double j = floor_(u1 * n);
+    return p[0] + (j < n ? j : n - 1.0);
+  } else if constexpr (D == M355_DISCRETEWEIBULL) {  // discreteweibull.py:78-79: ppf(uniform)
+    double u1, u2;
+    next_pair(st, u1, u2);
+    const double v = __builtin_ceil(pow_(flog(1.0 - u1) / flog(p[0]), 1.0 / p[1]) - 1.0);
+    return v < 0.0 ? 0.0 : v;
+  } else if constexpr (D == M355_NEGATIVEBINOMIAL) {  // negativebinomial.py:66-67: Poisson(Gamma(n, (1-p)/p))
+    const double lam = sample_std_gamma(st, p[0]) * ((1.0 - p[1]) / p[1]);
+    return sample_poisson(st, lam);
+  } else if constexpr (D == M355_BETABINOMIAL) {  // betabinomial.py:111-112: binomial(n, Beta(alpha, beta))
+    const double ga = sample_std_gamma(st, p[1]);
+    const double gb = sample_std_gamma(st, p[2]);
+    return sample_binomial(st, p[0], ga / (ga + gb));
+  } else if constexpr (D == M355_HYPERGEOMETRIC) {  // hypergeometric.py:115-116: n draws without replacement
+    double good = p[1], total = p[0], x = 0.0;
+    const int draws = (int)p[2];
+    for (int i = 0; i < draws; i += 2) {
+      double u1, u2;
+      next_pair(st, u1, u2);
+      if (u1 * total < good) { x += 1.0; good -= 1.0; }
+      total -= 1.0;
+      if (i + 1 < draws) {
+        if (u2 * total < good) { x += 1.0; good -= 1.0; }
+        total -= 1.0;
+      }
+    }
+    return x;
+  } else if constexpr (D == M355_ZI_POISSON || D == M355_ZI_BINOMIAL || D == M355_ZI_NEGATIVEBINOMIAL) {
+    // zi_*.py rvs: base draw times a Bernoulli(psi) mask
+    double u1, u2;
+    next_pair(st, u1, u2);
+    double base;
+    if constexpr (D == M355_ZI_POISSON) base = sample_poisson(st, p[1]);
+    else if constexpr (D == M355_ZI_BINOMIAL) base = sample_binomial(st, p[1], p[2]);
+    else base = sample_poisson(st, sample_std_gamma(st, p[1]) * ((1.0 - p[2]) / p[2]));
+    return (u1 < p[0]) ? base : 0.0;
   } else if constexpr (D == M355_INVERSEGAMMA) {  // inversegamma.py:69-70: 1 / Gamma(alpha, rate beta)
     return p[1] / sample_std_gamma(st, p[0]);
   } else if constexpr (D == M355_CHISQUARED) {  // chisquared.py:59-60

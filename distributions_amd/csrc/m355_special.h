@@ -451,7 +451,7 @@ M355_DEV_HEAVY double betainc_xy(double a, double b, double x, double y, double 
     // 1 - r cancels when the answer is small; where the (slow but direct) power series of the
     // unflipped problem applies, use it instead.  After the swap that problem is I_y(b, a).
     if (r > 0.9 && a * y <= 1.0 && y <= 0.95) return betainc_pseries(b, a, y, lbeta);
-    r = (r <= kEps) ? 1.0 - kEps : 1.0 - r;
+    r = 1.0 - r;  // (correctly rounded: 1 when the tail is below eps/2, as SciPy's betainc gives)
   }
   return r;
 }

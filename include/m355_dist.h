@@ -74,7 +74,17 @@ enum m355_dist {
   M355_SCALEDINVERSECHISQUARED = 25,   /* scaledinversechisquared.py */
   M355_HALFSTUDENTT = 26,              /* halfstudentt.py */
   M355_BETASCALED = 27,                /* betascaled.py */
-  M355_DIST_COUNT = 28
+  M355_BERNOULLI = 28,                 /* bernoulli.py */
+  M355_GEOMETRIC = 29,                 /* geometric.py */
+  M355_DISCRETEUNIFORM = 30,           /* discreteuniform.py */
+  M355_DISCRETEWEIBULL = 31,           /* discreteweibull.py */
+  M355_NEGATIVEBINOMIAL = 32,          /* negativebinomial.py */
+  M355_BETABINOMIAL = 33,              /* betabinomial.py */
+  M355_HYPERGEOMETRIC = 34,            /* hypergeometric.py */
+  M355_ZI_POISSON = 35,                /* zi_poisson.py */
+  M355_ZI_BINOMIAL = 36,               /* zi_binomial.py */
+  M355_ZI_NEGATIVEBINOMIAL = 37,       /* zi_negativebinomial.py */
+  M355_DIST_COUNT = 38
 };
 
 /* function ids: the reference function of that module */
@@ -114,7 +124,9 @@ int m355_device_count(void);
  * M355_F64 or M355_F32.  Parameter order is the reference's (normal: mu, sigma; gamma: alpha,
  * beta; beta: alpha, beta; studentt: nu, mu, sigma; poisson: mu; binomial: n, p; the closed-form
  * and re-parameterised families of SURVEY.md 8(f) rank 1 likewise, e.g. weibull: alpha, beta;
- * triangular: lower, c, upper; betascaled: alpha, beta, lower, upper -- at most four parameters).
+ * triangular: lower, c, upper; betascaled: alpha, beta, lower, upper -- at most four parameters; the discrete
+ * families of rank 2 -- bernoulli ... zi_negativebinomial -- too, their ppf / isf by find_ppf_discrete,
+ * optimization.py:102-129, where the reference uses it).
  */
 int m355_elemwise(int dist, int fn, int out_dtype, int64_t n, const m355_operand* x, int nparams,
                   const m355_operand* params, void* out, void* stream);

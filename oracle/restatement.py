@@ -662,3 +662,8 @@ TABLE = {
 from . import restatement_families as _families  # noqa: E402
 
 TABLE.update(_families.FAMILY_TABLE)
+
+# discrete families
+from . import restatement_discrete as _discrete  # noqa: E402
+
+TABLE.update(_discrete.DISCRETE_TABLE)

@@ -100,7 +100,60 @@ def grids():
         g.append(("binomial", stats.binom, [n, p], {"n": n, "p": p}, (0, n),
                   {"logsf_rtol": lrt}))
     g.extend(family_grids())
+    g.extend(discrete_grids())
     return g
+
+
+def discrete_grids():
+    """The reference's SciPy grids for the discrete families (tests/test_<dist>.py of the reference:
+    bernoulli :9-17, geometric :10-17, discreteuniform :9-18, negativebinomial :9-18, betabinomial
+    :10-29, hypergeometric :10-20).  discreteweibull and the zero-inflated families are tested only
+    empirically by the reference (no SciPy counterpart): see ZI_CASES / DWEIBULL_CASES."""
+    from scipy import stats
+
+    inf = float("inf")
+    g = []
+    for p in [0.3, 0.5, 0.001, 0.999]:
+        g.append(("bernoulli", stats.bernoulli, [p], {"p": p}, (0, 1), {}))
+    for p in [0.1, 0.5, 0.9]:
+        g.append(("geometric", stats.geom, [p], {"p": p}, (1, inf), {}))
+    for lo, hi in [(-2, 1), (0, 5), (-10, -5), (1, 10), (0, 0)]:
+        g.append(("discreteuniform", stats.randint, [float(lo), float(hi)], {"low": lo, "high": hi + 1}, (lo, hi), {}))
+    for n, p in [(2.1, 0.375), (1.0, 0.8), (10.0, 0.1), (0.5, 0.9), (20.0, 0.05)]:
+        g.append(("negativebinomial", stats.nbinom, [n, p], {"n": n, "p": p}, (0, inf), {}))
+    for n, a, b in [(10, 2.0, 3.0), (6, 1.0, 1.0), (20, 0.5, 0.5), (15, 5.0, 2.0), (100, 20.0, 20.0), (10, 1.0, 3.0),
+                    (10, 3.0, 1.0)]:
+        g.append(("betabinomial", stats.betabinom, [float(n), a, b], {"n": n, "a": a, "b": b}, (0, n), {}))
+    for N, k, n in [(20, 7, 12), (15, 10, 8), (50, 20, 10)]:
+        g.append(("hypergeometric", stats.hypergeom, [float(N), float(k), float(n)], {"M": N, "n": k, "N": n},
+                  (max(0, n + k - N), min(k, n)), {}))
+    return g
+
+
+# parameter sets of the reference's empirical tests (tests/test_discreteweibull.py:9-16,
+# test_zi_poisson.py:11-19, test_zi_binomial.py:20-28, test_zi_negativebinomial.py:17-25)
+DWEIBULL_CASES = [(0.8, 2.0), (0.5, 1.5), (0.3, 1.0), (0.9, 3.0)]
+ZI_CASES = {
+    "zi_poisson": [(0.7, 2.0), (0.5, 5.0), (0.9, 1.0), (0.3, 10.0), (0.8, 0.5)],
+    "zi_binomial": [(0.7, 10.0, 0.3), (0.5, 20.0, 0.5), (0.9, 5.0, 0.2), (0.3, 15.0, 0.7), (0.8, 8.0, 0.4)],
+    "zi_negativebinomial": [(0.7, 5.0, 0.4), (0.5, 10.0, 0.3), (0.9, 2.0, 0.5), (0.6, 3.0, 0.6), (0.8, 8.0, 0.2)],
+}
+
+
+def empirical_discrete_cases():
+    """(name, params) of the discrete families that have no SciPy counterpart."""
+    out = [("discreteweibull", list(c)) for c in DWEIBULL_CASES]
+    for name, cases in ZI_CASES.items():
+        out.extend((name, list(c)) for c in cases)
+    return out
+
+
+def discrete_points(rng, hi=60, n=4000):
+    """Integer and non-integer evaluation points + probabilities for a discrete family on 0..hi."""
+    xs = np.concatenate([rng.integers(-3, hi, n).astype(np.float64), rng.uniform(-2, hi, n // 4),
+                         [-np.inf, -1.0, -0.5, 0.0, 0.5, 1.0, float(hi), 1e6, np.inf]])
+    qs = np.concatenate([rng.uniform(0, 1, n), ISF_POINTS, [1e-300, 1e-12, 1 - 1e-12]])
+    return xs, qs
 
 
 def family_grids():
@@ -187,7 +240,10 @@ def cancellation_ok(fn, got, exp, abs_tol=2e-13):
     if fn not in ("logcdf", "logsf"):
         return np.zeros(got.shape, dtype=bool)
     with np.errstate(all="ignore"):
-        return np.abs(np.exp(got) - np.exp(exp)) <= abs_tol
+        pg, pe = np.exp(got), np.exp(exp)
+        # log(1 - cdf) of a probability below the rounding noise of the sum (betabinomial.sf = 1 - sum of pmf,
+        # betabinomial.py:87-104) is log(+-noise): NaN on one side is the same information as ~-30 on the other
+        return (np.abs(pg - pe) <= abs_tol) | (np.isnan(got) & (pe <= abs_tol)) | (np.isnan(exp) & (pg <= abs_tol))
 
 
 # halfstudentt.cdf (halfstudentt.py:84-91) feeds betainc the argument nu / (x_norm^2 + nu), which

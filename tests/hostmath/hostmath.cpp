@@ -3,7 +3,7 @@
 // GPU is attached.  The hardware seeds (v_rcp_f64, v_frexp_*) and the device libm (lgamma, exp,
 // erfc) are replaced by host equivalents, so this is NOT the parity test: parity is tests -m gpu.
 #include "../../distributions_amd/csrc/m355_dist_list.h"
-#include "../../distributions_amd/csrc/m355_dists2.h"
+#include "../../distributions_amd/csrc/m355_dists3.h"
 
 using namespace m355;
 
@@ -73,12 +73,10 @@ template <int D> static void rvs_loop(long n, const double* p, unsigned long lon
 extern "C" int hm_rvs(int dist, long n, const double* p, unsigned long long seed, unsigned stream,
                       unsigned long long offset, double* out) {
   switch (dist) {
-    case M355_NORMAL: rvs_loop<M355_NORMAL>(n, p, seed, stream, offset, out); return 0;
-    case M355_GAMMA: rvs_loop<M355_GAMMA>(n, p, seed, stream, offset, out); return 0;
-    case M355_BETA: rvs_loop<M355_BETA>(n, p, seed, stream, offset, out); return 0;
-    case M355_STUDENTT: rvs_loop<M355_STUDENTT>(n, p, seed, stream, offset, out); return 0;
-    case M355_POISSON: rvs_loop<M355_POISSON>(n, p, seed, stream, offset, out); return 0;
-    case M355_BINOMIAL: rvs_loop<M355_BINOMIAL>(n, p, seed, stream, offset, out); return 0;
+#define HM_RVS_CASE(ID, name, np) \
+  case ID: rvs_loop<ID>(n, p, seed, stream, offset, out); return 0;
+    M355_DIST_LIST(HM_RVS_CASE)
+#undef HM_RVS_CASE
   }
   return -1;
 }

@@ -238,3 +238,40 @@ def test_logitnormal(gpu, mu, sigma):
     assert np.allclose(logitnormal.cdf(logitnormal.ppf(q, mu, sigma), mu, sigma), q, rtol=0, atol=1e-9)
     assert np.allclose(logitnormal.sf(xs, mu, sigma) + logitnormal.cdf(xs, mu, sigma), 1.0, atol=1e-12)
     assert np.array_equal(logitnormal.isf(q, mu, sigma), logitnormal.ppf(1 - q, mu, sigma))
+
+
+def _discrete_cases():
+    out = [(g[0], list(g[2]), g[4]) for g in H.discrete_grids()]
+    out += [(n, p, (0, 60)) for n, p in H.empirical_discrete_cases()]
+    return out
+
+
+@pytest.mark.parametrize("name, params, support", _discrete_cases(),
+                         ids=[f"{n}-{'-'.join(map(str, p))}" for n, p, _ in _discrete_cases()])
+def test_discrete_families_dense_parity(gpu, name, params, support):
+    """Discrete families, every function on integer and non-integer points
+    (float64 and int64 observations): values at 1e-12, ppf / isf -- the integer results of
+    find_ppf_discrete (optimization.py:102-129), cycles of the iteration included -- bit-exact."""
+    rng = np.random.default_rng(19)
+    hi = 60 if not np.isfinite(support[1]) else int(support[1]) + 4
+    xs, qs = H.discrete_points(rng, hi=max(hi, 8), n=20_000)
+    m = mod(name)
+    for fn in ALL_FNS:
+        pts = qs if fn in ("ppf", "isf") else xs
+        with np.errstate(all="ignore"):
+            exp = R.TABLE[f"{name}_{fn}"](pts, *params)
+        got = getattr(m, fn)(pts, *params)
+        if fn in ("ppf", "isf"):
+            ok = (got == exp) | (np.isnan(got) & np.isnan(exp))
+        else:
+            ok = H.close(got, exp) | H.cancellation_ok(fn, got, exp)
+        assert np.all(ok), (name, fn, params, pts[~ok][:4], got[~ok][:4], exp[~ok][:4])
+    k = rng.integers(-3, max(hi, 8), 5000)
+    with np.errstate(all="ignore"):
+        exp = R.TABLE[f"{name}_logpdf"](k.astype(np.float64), *params)
+    got = m.logpdf(k, *params)
+    assert np.array_equal(np.isneginf(got), np.isneginf(exp)) and np.all(H.close(got, exp))
+    fin = np.isfinite(exp)
+    if fin.any():
+        tot = m.sum_logpdf(k[fin], *params)
+        assert abs(tot - math.fsum(exp[fin])) <= 1e-12 * float(np.abs(exp[fin]).sum())

@@ -85,3 +85,22 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".h", ".hip")):
                 text = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in text.replace("the CPU oracle", ""), f
+
+
+def test_every_module_imports_with_the_reference_signatures():
+    """Each distribution module defines the reference's functions with its parameter names and order
+    (first argument x; q for ppf / isf, except discreteweibull whose own parameter is called q:
+    discreteweibull.py:53,65 write isf(x, q, beta) and ppf(p, q, beta))."""
+    import importlib
+    import inspect
+
+    from distributions_amd._lib import FN, PARAMS
+
+    for dist, names in PARAMS.items():
+        m = importlib.import_module(f"distributions_amd.{dist}")
+        for fn in FN:
+            sig = list(inspect.signature(getattr(m, fn)).parameters)
+            assert sig[1:] == list(names), (dist, fn, sig)
+            assert len(set(sig)) == len(sig)
+        assert list(inspect.signature(m.rvs).parameters) == list(names) + ["size", "random_state"]
+        assert list(inspect.signature(m.sum_logpdf).parameters) == ["x"] + list(names)

@@ -26,7 +26,7 @@ _dp = ctypes.POINTER(ctypes.c_double)
 @pytest.fixture(scope="session")
 def hostlib():
     csrc = os.path.join(HERE, "..", "distributions_amd", "csrc")
-    deps = [SRC] + [os.path.join(csrc, f) for f in ("m355_math.h", "m355_special.h", "m355_dists.h", "m355_dists2.h",
+    deps = [SRC] + [os.path.join(csrc, f) for f in ("m355_math.h", "m355_special.h", "m355_dists.h", "m355_dists2.h", "m355_dists3.h",
                                                     "m355_dist_list.h", "m355_rng.h")]
     if not os.path.exists(LIB) or any(os.path.getmtime(d) > os.path.getmtime(LIB) for d in deps):
         subprocess.check_call(["g++", "-O2", "-mfma", "-std=c++17", "-shared", "-fPIC", "-o", LIB, SRC])
@@ -229,4 +229,31 @@ def test_host_bodies_vs_oracle_1e12(hostlib, name, sp_dist, params, sp_params, s
             with np.errstate(all="ignore"):
                 ok |= np.isnan(exp) | (np.abs(got - exp) <= 1e-9 * np.maximum(1.0, np.abs(exp)))
             ok |= (pts < 1e-100) | (pts > 1 - 1e-15)
+        assert np.all(ok), (name, fn, params, pts[~ok][:5], got[~ok][:5], exp[~ok][:5])
+
+
+def _discrete_cases():
+    out = [(g[0], list(g[2]), g[4]) for g in H.discrete_grids()]
+    out += [(n, p, (0, 60)) for n, p in H.empirical_discrete_cases()]
+    return out
+
+
+@pytest.mark.parametrize("name, params, support", _discrete_cases(),
+                         ids=[f"{n}-{'-'.join(map(str, p))}" for n, p, _ in _discrete_cases()])
+def test_host_discrete_vs_oracle(hostlib, name, params, support):
+    """Discrete families on integer and non-integer points: values at 1e-12,
+    ppf / isf (integer results of find_ppf_discrete, optimization.py:102-129) bit-exact."""
+    rng = np.random.default_rng(9)
+    hi = 60 if not np.isfinite(support[1]) else int(support[1]) + 4
+    xs, qs = H.discrete_points(rng, hi=max(hi, 8), n=1500)
+    ns = host_namespace(hostlib, name, list(FN))
+    for fn in FN:
+        pts = qs if fn in ("ppf", "isf") else xs
+        with np.errstate(all="ignore"):
+            exp = R.TABLE[f"{name}_{fn}"](pts, *params)
+        got = getattr(ns, fn)(pts, *params)
+        if fn in ("ppf", "isf"):
+            ok = (got == exp) | (np.isnan(got) & np.isnan(exp))
+        else:
+            ok = _close(got, exp) | H.cancellation_ok(fn, got, exp)
         assert np.all(ok), (name, fn, params, pts[~ok][:5], got[~ok][:5], exp[~ok][:5])

@@ -123,6 +123,52 @@ def test_oracle_multinomial_constraints():
     assert R.multinomial_logpdf(np.array([5, 6]), 10, p) == -np.inf
 
 
+@pytest.mark.parametrize("name, params", H.empirical_discrete_cases(),
+                         ids=[f"{n}-{'-'.join(map(str, p))}" for n, p in H.empirical_discrete_cases()])
+def test_oracle_discrete_without_scipy(name, params):
+    """discreteweibull and the zero-inflated families have no SciPy counterpart (the reference tests
+    them against its own samples, tests/test_zi_poisson.py:11-50 etc.): the restatement is pinned on
+    the defining mixture / closed form written with scipy.stats, and ppf by brute force."""
+    ks = np.arange(0, 400, dtype=np.float64)
+    if name == "discreteweibull":
+        q, b = params
+        pmf = q ** (ks ** b) - q ** ((ks + 1) ** b)
+        cdf = 1 - q ** ((ks + 1) ** b)
+    else:
+        psi = params[0]
+        base = {"zi_poisson": lambda: stats.poisson(params[1]),
+                "zi_binomial": lambda: stats.binom(int(params[1]), params[2]),
+                "zi_negativebinomial": lambda: stats.nbinom(params[1], params[2])}[name]()
+        pmf = psi * base.pmf(ks) + (1 - psi) * (ks == 0)
+        cdf = (1 - psi) + psi * base.cdf(ks)
+    ns = H.oracle_namespace(name)
+    with np.errstate(all="ignore"):
+        assert_allclose(ns.pdf(ks, *params), pmf, rtol=1e-9, atol=1e-300)
+        assert_allclose(np.exp(ns.logpdf(ks, *params)), pmf, rtol=1e-9, atol=1e-300)
+        assert_allclose(ns.cdf(ks, *params), cdf, rtol=1e-9)
+        # quirk kept: discreteweibull.cdf (discreteweibull.py:49-50), poisson.cdf (poisson.py:49-50) and
+        # binomial.cdf do not floor x; negativebinomial.cdf (negativebinomial.py:46-48) does
+        if name == "zi_negativebinomial":
+            assert_allclose(ns.cdf(ks + 0.5, *params), cdf, rtol=1e-9)
+        assert_allclose(ns.sf(ks, *params), 1 - cdf, rtol=1e-6, atol=1e-14)
+        assert_allclose(np.exp(ns.logcdf(ks, *params)), cdf, rtol=1e-9)
+        assert_allclose(np.exp(ns.logsf(ks, *params)), 1 - cdf, rtol=1e-6, atol=1e-14)
+        assert np.all(ns.pdf(np.array([-1.0, -np.inf]), *params) == 0)
+        assert np.all(ns.cdf(np.array([-1.0, -np.inf]), *params) == 0) and ns.cdf(np.inf, *params) == 1
+    qs = np.random.default_rng(4).uniform(0.001, 0.999, 500)
+    brute = np.searchsorted(ns.cdf(ks, *params), qs, side="left").astype(np.float64)
+    got = ns.ppf(qs, *params)
+    # find_ppf_discrete (optimization.py:102-129) cycles between the bounds for some q of the
+    # zero-inflated families (e.g. 20 -> 0 -> 1 -> 20 for zi_binomial(0.5, 20, 0.5)) and then returns
+    # wherever iteration 100 stands: the restatement keeps that, so only converged points are compared
+    conv = (ns.cdf(got, *params) >= qs - 1e-7) & (ns.cdf(got - 1, *params) < qs)
+    assert conv.mean() > 0.3
+    assert np.array_equal(got[conv], brute[conv])
+    assert np.array_equal(ns.isf(qs, *params), ns.ppf(1 - qs, *params))
+    edge = ns.ppf(np.array([-0.1, 1.1]), *params)
+    assert np.all(np.isnan(edge))
+
+
 def test_oracle_edge_table_survey_appendix_c():
     """Edge values recorded in SURVEY.md Appendix C (literal float64 restatement)."""
     inf = np.inf

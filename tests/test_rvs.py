@@ -15,7 +15,7 @@ from tests.test_hostmath import hostlib  # noqa: F401  (fixture)
 
 _dp = ctypes.POINTER(ctypes.c_double)
 _u32p = ctypes.POINTER(ctypes.c_uint32)
-DIST = {"normal": 0, "gamma": 1, "beta": 2, "studentt": 3, "poisson": 4, "binomial": 5}
+from distributions_amd._lib import DIST  # ids of include/m355_dist.h (pure Python, no library load)
 
 CONT = [
     ("normal", (0.3, 1.7), stats.norm(0.3, 1.7)),
@@ -40,7 +40,7 @@ DISC = [
 def host_rvs(lib, name, n, params, seed=20260313, stream=None, offset=0):
     lib.hm_rvs.argtypes = [ctypes.c_int, ctypes.c_long, _dp, ctypes.c_ulonglong, ctypes.c_uint,
                            ctypes.c_ulonglong, _dp]
-    p = np.array(list(params) + [0, 0, 0], dtype=np.float64)[:3].copy()
+    p = np.array(list(params) + [0, 0, 0, 0], dtype=np.float64)[:4].copy()
     out = np.empty(n)
     stream = DIST[name] if stream is None else stream
     assert lib.hm_rvs(DIST[name], n, p.ctypes.data_as(_dp), seed, stream, offset, out.ctypes.data_as(_dp)) == 0
@@ -101,6 +101,70 @@ def test_host_sampler_continuous_ks(hostlib, name, params, d):
 def test_host_sampler_discrete_chi2(hostlib, name, params, d):
     x = host_rvs(hostlib, name, 400_000, params)
     assert np.all(x == np.floor(x)) and x.min() >= 0
+    assert chi2_pvalue(x, d) > 1e-3
+    assert moments_ok(x, d)
+
+
+class OracleDiscrete:
+    """pmf / cdf / sf / moments of a discrete family taken from the oracle (for the families SciPy
+    does not have: discreteweibull and the zero-inflated ones)."""
+
+    def __init__(self, name, params, hi=2000):
+        self.name, self.params = name, params
+        self.ks = np.arange(0, hi, dtype=np.float64)
+        self.p = R.TABLE[f"{name}_pdf"](self.ks, *params)
+
+    def pmf(self, k):
+        return R.TABLE[f"{self.name}_pdf"](np.asarray(k, dtype=np.float64), *self.params)
+
+    def cdf(self, k):
+        return R.TABLE[f"{self.name}_cdf"](np.asarray(k, dtype=np.float64), *self.params)
+
+    def sf(self, k):
+        return R.TABLE[f"{self.name}_sf"](np.asarray(k, dtype=np.float64), *self.params)
+
+    def mean(self):
+        return float((self.ks * self.p).sum())
+
+    def var(self):
+        return float((self.ks ** 2 * self.p).sum() - self.mean() ** 2)
+
+    def stats(self, moments="k"):
+        m, v = self.mean(), self.var()
+        return float((((self.ks - m) ** 4) * self.p).sum() / v ** 2 - 3.0)
+
+
+# rvs of the discrete families (SURVEY.md 8(f) rank 2); the SciPy objects are the ones the reference's own
+# tests compare with (tests/test_bernoulli.py ... test_hypergeometric.py of the reference)
+DISC_FAMILIES = [
+    ("bernoulli", (0.3,), lambda: stats.bernoulli(0.3)),
+    ("bernoulli", (0.999,), lambda: stats.bernoulli(0.999)),
+    ("geometric", (0.1,), lambda: stats.geom(0.1)),
+    ("geometric", (0.9,), lambda: stats.geom(0.9)),
+    ("discreteuniform", (-2.0, 5.0), lambda: stats.randint(-2, 6)),
+    ("negativebinomial", (2.1, 0.375), lambda: stats.nbinom(2.1, 0.375)),
+    ("negativebinomial", (20.0, 0.05), lambda: stats.nbinom(20.0, 0.05)),   # Poisson leg on PTRS
+    ("negativebinomial", (0.5, 0.9), lambda: stats.nbinom(0.5, 0.9)),       # gamma shape < 1
+    ("betabinomial", (10.0, 2.0, 3.0), lambda: stats.betabinom(10, 2.0, 3.0)),
+    ("betabinomial", (100.0, 20.0, 20.0), lambda: stats.betabinom(100, 20.0, 20.0)),
+    ("betabinomial", (20.0, 0.5, 0.5), lambda: stats.betabinom(20, 0.5, 0.5)),
+    ("hypergeometric", (20.0, 7.0, 12.0), lambda: stats.hypergeom(M=20, n=7, N=12)),
+    ("hypergeometric", (50.0, 20.0, 10.0), lambda: stats.hypergeom(M=50, n=20, N=10)),
+    ("discreteweibull", (0.8, 2.0), lambda: OracleDiscrete("discreteweibull", (0.8, 2.0))),
+    ("discreteweibull", (0.9, 3.0), lambda: OracleDiscrete("discreteweibull", (0.9, 3.0))),
+    ("zi_poisson", (0.7, 2.0), lambda: OracleDiscrete("zi_poisson", (0.7, 2.0))),
+    ("zi_poisson", (0.3, 10.0), lambda: OracleDiscrete("zi_poisson", (0.3, 10.0))),
+    ("zi_binomial", (0.5, 20.0, 0.5), lambda: OracleDiscrete("zi_binomial", (0.5, 20.0, 0.5))),
+    ("zi_negativebinomial", (0.7, 5.0, 0.4), lambda: OracleDiscrete("zi_negativebinomial", (0.7, 5.0, 0.4))),
+]
+_DISC_IDS = [f"{c[0]}-{c[1]}" for c in DISC_FAMILIES]
+
+
+@pytest.mark.parametrize("name, params, make", DISC_FAMILIES, ids=_DISC_IDS)
+def test_host_sampler_discrete_families_chi2(hostlib, name, params, make):
+    d = make()
+    x = host_rvs(hostlib, name, 400_000, params)
+    assert np.all(x == np.floor(x))
     assert chi2_pvalue(x, d) > 1e-3
     assert moments_ok(x, d)
 
@@ -249,3 +313,24 @@ def test_gpu_rvs_logitnormal(gpu):
     x = logitnormal.rvs(-1.0, 1.0, size=200_000, random_state=5)
     z = np.log(x) - np.log1p(-x)
     assert stats.kstest(z, stats.norm(-1.0, 1.0).cdf).pvalue > 1e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name, params, make", DISC_FAMILIES, ids=_DISC_IDS)
+def test_gpu_rvs_discrete_families(gpu, hostlib, name, params, make):
+    """rvs of the discrete families: int64 draws, chi-square against the reference's distribution,
+    draw-by-draw agreement with the host build, determinism and partition invariance."""
+    import importlib
+
+    m = importlib.import_module(f"distributions_amd.{name}")
+    d = make()
+    n = 1_000_000
+    x = m.rvs(*params, size=n, random_state=20260313)
+    assert x.shape == (n,) and x.dtype == np.int64
+    assert chi2_pvalue(x, d) > 1e-3
+    assert moments_ok(x.astype(np.float64), d)
+    h = host_rvs(hostlib, name, 200_000, params)
+    assert (x[:200_000] == h).mean() > 0.9999
+    k = 77_777
+    assert np.array_equal(x[:200_000], np.concatenate([m.rvs(*params, size=k, random_state=(20260313, 0)),
+                                                       m.rvs(*params, size=200_000 - k, random_state=(20260313, k))]))
