@@ -148,6 +148,30 @@ def config6(torch, n):
         del x
 
 
+def config7(torch, n):
+    """Gradient path: value + gradient of the summed log-likelihood in one pass, n fp64
+    points, scalar parameters.  Algorithmic bytes: 8 B/element without dx (read x), 16 B/element with dx."""
+    from distributions_amd import _dispatch, raw
+
+    cases = {"normal": (0.3, 1.7), "gamma": (2.5, 1.3), "beta": (2.0, 5.0), "studentt": (5.0, 0.0, 2.0),
+             "lognormal": (2.0, 0.5), "weibull": (2.0, 5.0), "cauchy": (-5.0, 0.5), "logistic": (2.5, 4.0),
+             "inversegamma": (5.0, 2.0), "betascaled": (2.0, 5.0, -1.0, 3.0)}
+    dev = torch.device("cuda", 0)
+    dx = torch.empty(n, dtype=torch.float64, device=dev)
+    sums = torch.zeros(8, dtype=torch.float64, device=dev)
+    ws = raw.sumlogp_workspace(dev)
+    for name, p in cases.items():
+        x = _dispatch.rvs(name, p, size=n, random_state=3, as_torch=True)
+        ms0 = timed(torch, lambda: raw.logpdf_grad_into(name, x, p, sums, None, ws), reps=5)
+        ms1 = timed(torch, lambda: raw.logpdf_grad_into(name, x, p, sums, dx, ws), reps=5)
+        ms2 = timed(torch, lambda: raw.sumlogp_into(name, "logpdf", x, p, sums, ws), reps=5)
+        print(json.dumps({"config": 7, "dist": name, "n": n, "value_and_param_grads_ms": round(ms0, 4),
+                          "GB_per_s": round(8.0 * n / (ms0 * 1e-3) / 1e9, 1), "with_dx_ms": round(ms1, 4),
+                          "with_dx_GB_per_s": round(16.0 * n / (ms1 * 1e-3) / 1e9, 1),
+                          "sum_logpdf_only_ms": round(ms2, 4)}), flush=True)
+        del x
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--config", default="all")
@@ -164,6 +188,8 @@ def main():
         config4(torch, args.n or 100_000)
     if args.config in ("6", "all"):
         config6(torch, args.n or 100_000_000)
+    if args.config in ("7", "all"):
+        config7(torch, args.n or 100_000_000)
 
 
 if __name__ == "__main__":

@@ -209,6 +209,74 @@ def sumlogp(dist: str, fn: str, x: Any, *params: Any):
     return float(out.item())
 
 
+# -------------------------------------------------------------------------------------- gradient
+def _unbroadcast(t, shape, torch):
+    """Sum a tensor of the broadcast shape down to an operand's shape (what PyTensor's Elemwise L_op
+    does with the gradient of a broadcast input)."""
+    shape = tuple(shape)
+    if tuple(t.shape) == shape:
+        return t
+    lead = t.dim() - len(shape)
+    if lead:
+        t = t.sum(dim=tuple(range(lead)))
+    axes = tuple(i for i, (a, b) in enumerate(zip(t.shape, shape)) if b == 1 and a != 1)
+    if axes:
+        t = t.sum(dim=axes, keepdim=True)
+    return t.reshape(shape)
+
+
+def logpdf_grad(dist: str, x: Any, *params: Any, elementwise: bool = False):
+    """Value and gradient of sum(<dist>.logpdf(x, *params)) in one pass over x (m355_logpdf_grad; what
+    pytensor.grad of the reference's graph gives).
+
+    elementwise=False: returns (total, [g_x, g_param_0, ...]) where every gradient has the shape of its
+    argument (scalar arguments get the summed partial straight from the kernel's reduction; array
+    arguments get the per-element partials, summed over the axes they were broadcast along).
+    elementwise=True: returns (total, [d logpdf/dx, d logpdf/dparam_0, ...]) per element of the
+    broadcast shape (the factors an Elemwise L_op multiplies with the output gradient)."""
+    if len(params) != NPARAMS[dist]:
+        raise TypeError(f"{dist}.logpdf takes {NPARAMS[dist]} parameters, got {len(params)}")
+    if dist not in _lib.GRAD:
+        raise NotImplementedError(f"{dist} has no gradient kernel")
+    torch = _torch()
+    L = _lib.lib()
+    args = (x, *params)
+    pl = plan(x, params)
+    device = _device_of(args, torch)
+    out_dt = torch.float32 if pl.out_f32 else torch.float64
+    np_ = len(params)
+    with torch.cuda.device(device):
+        sums = torch.zeros(2 + np_, dtype=torch.float64, device=device)
+        ws_bytes = int(L.m355_sumlogp_workspace_bytes())
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=device)
+        want = [elementwise or op.kind != "scalar" for op in pl.operands]
+        bufs = [torch.empty(pl.n, dtype=out_dt, device=device) if (w and pl.n) else None for w in want]
+        dptrs = (ctypes.c_void_p * max(np_, 1))(*[b.data_ptr() if b is not None else None for b in bufs[1:]])
+        ops, keep = _build_operands(pl, args, torch, device)
+        stream = torch.cuda.current_stream(device).cuda_stream
+        rc = L.m355_logpdf_grad(DIST[dist], F32 if pl.out_f32 else F64, pl.n, ctypes.byref(ops[0]), np_,
+                                ctypes.cast(ctypes.byref(ops, ctypes.sizeof(Operand)), ctypes.POINTER(Operand)),
+                                sums.data_ptr(), bufs[0].data_ptr() if bufs[0] is not None else None, dptrs,
+                                ws.data_ptr(), ws_bytes, stream)
+        _lib.check(rc)
+        del keep
+        grads = []
+        for j, (a, b) in enumerate(zip(args, bufs)):
+            if elementwise:
+                g = b.reshape(pl.shape) if b is not None else torch.zeros(pl.shape, dtype=out_dt, device=device)
+            elif b is None and pl.operands[j].kind != "scalar":  # empty broadcast shape
+                g = torch.zeros(_shape_of(a), dtype=out_dt, device=device)
+            elif b is None:
+                g = sums[1 + j].to(out_dt).reshape(_shape_of(a))
+            else:
+                g = _unbroadcast(b.reshape(pl.shape), _shape_of(a), torch)
+            grads.append(g)
+    if _wants_torch(args):
+        return sums[0].reshape(()), grads
+    host = sums.cpu().numpy()
+    return float(host[0]), [g.cpu().numpy() for g in grads]
+
+
 # ------------------------------------------------------------------------------------------- rvs
 _STREAM_ID = DIST  # Philox stream id = distribution id
 

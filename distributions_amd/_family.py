@@ -5,9 +5,10 @@ parameter names and order (``_lib.PARAMS``), each function one call into the C-A
 from __future__ import annotations
 
 from ._dispatch import elemwise as _elemwise
+from ._dispatch import logpdf_grad as _logpdf_grad
 from ._dispatch import rvs as _rvs
 from ._dispatch import sumlogp as _sumlogp
-from ._lib import FN, PARAMS
+from ._lib import FN, GRAD, PARAMS
 
 
 def export(ns: dict, dist: str, cites: dict | None = None) -> None:
@@ -38,3 +39,20 @@ def export(ns: dict, dist: str, cites: dict | None = None) -> None:
     loc["rvs"].__doc__ = (f"{dist}.py:{cites.get('rvs', '?')} of the reference; Philox counter-based draws, statistically "
                           "equivalent to the reference sampler (SURVEY.md quirk Q3).")
     ns["rvs"] = loc["rvs"]
+    if dist in GRAD:
+        export_grad(ns, dist)
+
+
+def export_grad(ns: dict, dist: str) -> None:
+    """sum_logpdf_grad / dlogpdf of `dist` (gradient path; the reference gets these from
+    pytensor.grad of its logpdf graph)."""
+    sig = ", ".join(PARAMS[dist])
+    loc: dict = {}
+    exec(f"def sum_logpdf_grad(x, {sig}):\n    return _g({dist!r}, x, {sig})\n"
+         f"def dlogpdf(x, {sig}):\n    return _g({dist!r}, x, {sig}, elementwise=True)[1]\n",
+         {"_g": _logpdf_grad}, loc)  # noqa: S102
+    loc["sum_logpdf_grad"].__doc__ = ("(sum(logpdf(x, ...)), [gradient w.r.t. x, w.r.t. each parameter]) in one pass; "
+                                      "every gradient has the shape of its argument.")
+    loc["dlogpdf"].__doc__ = "[d logpdf/dx, d logpdf/dparam_0, ...] per element of the broadcast shape."
+    ns["sum_logpdf_grad"] = loc["sum_logpdf_grad"]
+    ns["dlogpdf"] = loc["dlogpdf"]

@@ -58,6 +58,8 @@ DIST = {name: i for i, name in enumerate(PARAMS)}
 NPARAMS = {name: len(ps) for name, ps in PARAMS.items()}
 DISCRETE = ("poisson", "binomial", "bernoulli", "geometric", "discreteuniform", "discreteweibull", "negativebinomial",
             "betabinomial", "hypergeometric", "zi_poisson", "zi_binomial", "zi_negativebinomial")  # rvs returns int64
+# distributions with a gradient kernel (m355_grad_supported): the continuous families, poisson and binomial
+GRAD = tuple(n for n in PARAMS if n not in DISCRETE) + ("poisson", "binomial")
 FN = {"logpdf": 0, "logcdf": 1, "logsf": 2, "ppf": 3, "pdf": 4, "cdf": 5, "sf": 6, "isf": 7}
 
 
@@ -103,6 +105,10 @@ def lib():
     L.m355_sumlogp.argtypes = [i32, i32, i64, op, i32, op, vp, vp, sz, vp]
     L.m355_rvs.restype = i32
     L.m355_rvs.argtypes = [i32, i32, i64, i32, op, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint64, vp, vp]
+    L.m355_grad_supported.restype = i32
+    L.m355_grad_supported.argtypes = [i32]
+    L.m355_logpdf_grad.restype = i32
+    L.m355_logpdf_grad.argtypes = [i32, i32, i64, op, i32, op, vp, vp, ctypes.POINTER(vp), vp, sz, vp]
     _lib = L
     return L
 

@@ -117,6 +117,9 @@ int check_launch(int rc) {
 extern "C" int m355_rvs_impl(int dist, int out_dtype, long long n, const m355::GenericOps* ops, unsigned long long seed,
                              unsigned stream_id, unsigned long long offset, void* out, hipStream_t s);
 
+extern "C" int m355_grad_impl(int dist, long long n, const m355::GenericOps* ops, void* dx, void* const* dparams,
+                              int out_dtype, double* sums, double* partials, hipStream_t stream);
+
 extern "C" {
 
 int m355_version(void) { return M355_VERSION; }
@@ -175,6 +178,28 @@ int m355_sumlogp(int dist, int fn, int64_t n, const m355_operand* x, int nparams
   hipLaunchKernelGGL(k_final, dim3(1), dim3(m355::kBlock), 0, s, static_cast<const double*>(workspace), nblocks,
                      out_sum);
   return check_launch((int)hipGetLastError());
+}
+
+int m355_logpdf_grad(int dist, int out_dtype, int64_t n, const m355_operand* x, int nparams,
+                     const m355_operand* params, double* sums, void* dx, void* const* dparams, void* workspace,
+                     size_t workspace_bytes, void* stream) {
+  m355::LaunchArgs a{};
+  const int rc = build_args(dist, M355_LOGPDF, out_dtype, n, x, nparams, params, a);
+  if (rc != M355_OK) return rc;
+  if (!m355_grad_supported(dist)) return fail(M355_ERR_UNSUPPORTED, "distribution %d has no gradient kernel", dist);
+  if (sums == nullptr || workspace == nullptr) return fail(M355_ERR_INVALID, "sums and workspace must not be NULL");
+  if (workspace_bytes < m355_sumlogp_workspace_bytes())
+    return fail(M355_ERR_WORKSPACE, "workspace of %zu bytes is smaller than the required %zu", workspace_bytes,
+                m355_sumlogp_workspace_bytes());
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (n == 0) {
+    hipError_t e = hipMemsetAsync(sums, 0, sizeof(double) * (2 + nparams), s);
+    return e == hipSuccess ? M355_OK : fail(M355_ERR_LAUNCH, "hipMemsetAsync: %s", hipGetErrorString(e));
+  }
+  m355::GenericOps ops;
+  ops.x = a.x;
+  for (int q = 0; q < m355::kMaxParams; ++q) ops.p[q] = a.p[q];
+  return check_launch(m355_grad_impl(dist, n, &ops, dx, dparams, out_dtype, sums, static_cast<double*>(workspace), s));
 }
 
 int m355_rvs(int dist, int out_dtype, int64_t n, int nparams, const m355_operand* params, uint64_t seed,

@@ -55,3 +55,8 @@ def rvs(alpha, beta, size=None, random_state=None):
     """gamma.py:61-62 (shape alpha, scale 1/beta) of the reference; Philox counter-based draws, KS / chi-square equivalent to
     the reference sampler (not NumPy-stream-equal)."""
     return _rvs("gamma", (alpha, beta,), size=size, random_state=random_state)
+
+
+from ._family import export_grad as _export_grad  # noqa: E402
+
+_export_grad(globals(), "gamma")

@@ -52,3 +52,18 @@ def sumlogp_into(dist: str, fn: str, x, params, out_sum, workspace) -> None:
     stream = torch.cuda.current_stream(x.device).cuda_stream
     _lib.check(_lib.lib().m355_sumlogp(DIST[dist], FN[fn], x.numel(), _p(ops, 0), len(params), _p(ops, 1),
                                        out_sum.data_ptr(), workspace.data_ptr(), workspace.numel(), stream))
+
+
+def logpdf_grad_into(dist: str, x, params, sums, dx, workspace) -> None:
+    """sums: float64 CUDA tensor of >= 2 + len(params) elements ([sum logpdf, sum d/dx, sum d/dparam_j ...]);
+    dx: CUDA tensor like x for the per-element d logpdf/dx, or None."""
+    import torch
+
+    assert x.is_cuda and x.is_contiguous() and sums.dtype == torch.float64 and sums.numel() >= 2 + len(params)
+    assert dx is None or (dx.is_cuda and dx.is_contiguous() and dx.numel() == x.numel())
+    ops = _operands(x, params, torch)
+    stream = torch.cuda.current_stream(x.device).cuda_stream
+    _lib.check(_lib.lib().m355_logpdf_grad(DIST[dist], _dt(dx, torch) if dx is not None else F64, x.numel(), _p(ops, 0),
+                                           len(params), _p(ops, 1), sums.data_ptr(),
+                                           dx.data_ptr() if dx is not None else None, None, workspace.data_ptr(),
+                                           workspace.numel(), stream))

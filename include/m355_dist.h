@@ -144,6 +144,27 @@ int m355_sumlogp(int dist, int fn, int64_t n, const m355_operand* x, int nparams
                  size_t workspace_bytes, void* stream);
 
 /*
+ * Value and gradient of the summed log-likelihood in one pass.  The reference has no
+ * function for this: its logpdf graphs (e.g. normal.py:79-80, gamma.py:77-82, beta.py:102-108,
+ * studentt.py:108-119 and the closed-form families) are differentiated by pytensor.grad; this entry point
+ * is what the L_op of a custom Op over m355_elemwise / m355_sumlogp calls.
+ *   sums (device, 2 + nparams doubles): [sum logpdf, sum d/dx, sum d/dparam_0, ...] over the n elements of
+ *        the broadcast of (x, params) -- for scalar parameters sums[2 + j] is d(sum logpdf)/d(param_j).
+ *   dx (device, n elements of out_dtype, or NULL): d logpdf / dx per element.
+ *   dparams (host array of nparams device pointers, or NULL; entries may be NULL): d logpdf / d param_j
+ *        per element of the broadcast shape (the caller reduces over the axes the parameter was broadcast
+ *        along -- what PyTensor's Elemwise L_op does).
+ * Partials follow PyTensor's rules for the primitives of the graph (xlogy0, switch as a select of the taken
+ * arm: all partials are 0 outside the support).  Defined for the continuous families (ids 0-3, 6-27) and, with
+ * respect to the parameters (and formally x), poisson and binomial; m355_grad_supported(dist) tells.
+ * `workspace`: as for m355_sumlogp (same size).  Deterministic (fixed-order reduction).
+ */
+int m355_grad_supported(int dist);
+int m355_logpdf_grad(int dist, int out_dtype, int64_t n, const m355_operand* x, int nparams,
+                     const m355_operand* params, double* sums, void* dx, void* const* dparams,
+                     void* workspace, size_t workspace_bytes, void* stream);
+
+/*
  * out[i] = one draw of `dist` with the parameters of element i, i in [0, n): replaces
  * pt.random.{normal,gamma,beta,t,poisson,binomial}(..., rng, size) -> numpy.random.Generator
  * (normal.py:66-67, gamma.py:61-62 [shape alpha, scale 1/beta], beta.py:86-87, studentt.py:96-97,

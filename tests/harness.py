@@ -270,3 +270,21 @@ def ppf_unpinned(name, fn, pts):
         q = 1.0 - pts if fn == "isf" else pts
         return (q < 1e-100) | (q > 1 - 1e-15)
     return np.zeros(np.shape(pts), dtype=bool)
+
+
+def grad_close(got, exp, info, tol=1e-12):
+    """Parity criterion of the gradient path: the value (slot 0) at |a-b| <= tol * max(1, |b|); a partial at
+    tol * max(1, |b|, largest partial of the element) -- the partials of one element are sums of the same
+    few terms (e.g. lognormal's d/dsigma = (z^2 - 1)/sigma next to d/dx ~ z/(sigma x)), so the rounding
+    of the largest one is the floor for all of them.  Asserts with the offending points; returns True."""
+    exp = [np.asarray(e, dtype=np.float64) for e in exp]
+    with np.errstate(all="ignore"):
+        scale = np.maximum(1.0, np.nanmax(np.where(np.isfinite(np.stack(exp[1:])), np.abs(np.stack(exp[1:])), 0.0), axis=0))
+    for s, e in enumerate(exp):
+        g = np.asarray(got[s], dtype=np.float64)
+        same = (g == e) | (np.isnan(g) & np.isnan(e))
+        with np.errstate(all="ignore"):
+            lim = tol * (np.maximum(1.0, np.abs(e)) if s == 0 else np.maximum(scale, np.abs(e)))
+            ok = same | (np.abs(g - e) <= lim)
+        assert np.all(ok), (info[:2], "slot", s, np.asarray(info[2])[~ok][:4], g[~ok][:4], e[~ok][:4])
+    return True

@@ -4,6 +4,7 @@
 // erfc) are replaced by host equivalents, so this is NOT the parity test: parity is tests -m gpu.
 #include "../../distributions_amd/csrc/m355_dist_list.h"
 #include "../../distributions_amd/csrc/m355_dists3.h"
+#include "../../distributions_amd/csrc/m355_grad.h"
 
 using namespace m355;
 
@@ -80,3 +81,25 @@ extern "C" int hm_rvs(int dist, long n, const double* p, unsigned long long seed
   }
   return -1;
 }
+
+// Gradient path (csrc/m355_grad.h): out[i * (2 + NP) + s] = {logpdf, d/dx, d/dparam_0, ...} of element i.
+template <int D> static int grad_loop(long n, const double* x, const double* p, double* out) {
+  using G = Grad<D>;
+  if constexpr (!G::kHas) {
+    return -1;
+  } else {
+    const auto k = grad_pre<G>(p);
+    for (long i = 0; i < n; ++i) grad_eval<G>(x[i], k, out + i * (2 + G::NP));
+    return 0;
+  }
+}
+extern "C" int hm_grad(int dist, long n, const double* x, const double* p, double* out) {
+  switch (dist) {
+#define HM_GRAD_CASE(ID, name, np) \
+  case ID: return grad_loop<ID>(n, x, p, out);
+    M355_DIST_LIST(HM_GRAD_CASE)
+#undef HM_GRAD_CASE
+  }
+  return -1;
+}
+extern "C" void hm_digamma(long n, const double* x, double* out) { for (long i = 0; i < n; ++i) out[i] = digamma_(x[i]); }

@@ -26,7 +26,7 @@ _dp = ctypes.POINTER(ctypes.c_double)
 @pytest.fixture(scope="session")
 def hostlib():
     csrc = os.path.join(HERE, "..", "distributions_amd", "csrc")
-    deps = [SRC] + [os.path.join(csrc, f) for f in ("m355_math.h", "m355_special.h", "m355_dists.h", "m355_dists2.h", "m355_dists3.h",
+    deps = [SRC] + [os.path.join(csrc, f) for f in ("m355_math.h", "m355_special.h", "m355_dists.h", "m355_dists2.h", "m355_dists3.h", "m355_grad.h",
                                                     "m355_dist_list.h", "m355_rng.h")]
     if not os.path.exists(LIB) or any(os.path.getmtime(d) > os.path.getmtime(LIB) for d in deps):
         subprocess.check_call(["g++", "-O2", "-mfma", "-std=c++17", "-shared", "-fPIC", "-o", LIB, SRC])
@@ -257,3 +257,45 @@ def test_host_discrete_vs_oracle(hostlib, name, params, support):
         else:
             ok = _close(got, exp) | H.cancellation_ok(fn, got, exp)
         assert np.all(ok), (name, fn, params, pts[~ok][:5], got[~ok][:5], exp[~ok][:5])
+
+
+def test_host_digamma(hostlib):
+    rng = np.random.default_rng(12)
+    x = np.concatenate([np.exp(rng.uniform(np.log(1e-6), np.log(1e8), 50000)), -rng.uniform(0.01, 30, 2000),
+                        [1.0, 2.0, 0.5, 1.4616321449683623, 10.0, 1e-300, np.inf]])
+    got, exp = vec(hostlib, "hm_digamma", x), sp.digamma(x)
+    with np.errstate(all="ignore"):
+        near_pole = (x < 0) & (np.abs(x - np.round(x)) < 0.05)  # conditioned like 1 / distance to the pole
+    assert np.all(_close(got, exp, 1e-14) | near_pole)
+    assert np.all(_close(got, exp, 1e-11) | ~near_pole)
+    pos = (x > 0) & np.isfinite(x)
+    assert np.all(np.abs(got[pos] - exp[pos]) <= 2e-15 * np.maximum(1.0, np.abs(exp[pos])))
+
+
+def host_grad(lib, name, x, params):
+    x = np.ascontiguousarray(np.asarray(x, dtype=np.float64))
+    p = np.ascontiguousarray(np.asarray(list(params) + [0.0] * 4, dtype=np.float64)[:4])
+    out = np.empty((x.size, 2 + len(params)))
+    assert lib.hm_grad(DIST[name], ctypes.c_long(x.size), _ptr(x), _ptr(p), _ptr(out)) == 0
+    return out
+
+
+_GRAD_CASES = [g for g in H.grids() if g[0] in __import__("distributions_amd._lib", fromlist=["GRAD"]).GRAD]
+
+
+@pytest.mark.parametrize("name, sp_dist, params, sp_params, support, kw", _GRAD_CASES,
+                         ids=[f"{g[0]}-{'-'.join(str(v) for v in g[2])}" for g in _GRAD_CASES])
+def test_host_grad_vs_oracle(hostlib, name, sp_dist, params, sp_params, support, kw):
+    """Dual-number bodies of csrc/m355_grad.h against oracle/restatement_grad.py at 1e-12 (value and every
+    partial), on draws from the distribution plus the support ends and out-of-support points."""
+    from oracle import restatement_grad as G
+
+    if name == "logitnormal" or (name in ("studentt", "halfstudentt") and params[0] > 1e5):
+        pytest.skip("erfcx / device-libm-only arm: GPU-tested")
+    rng = np.random.default_rng(29)
+    d = sp_dist(**sp_params)
+    xs = np.concatenate([np.asarray(d.rvs(2000, random_state=rng), dtype=np.float64), H.extended_vals(d, support)])
+    xs = xs[np.isfinite(xs)]
+    got = host_grad(hostlib, name, xs, params)
+    val, grads = G.logpdf_grad(name, xs, *params)
+    assert H.grad_close(got.T, [val] + grads, (name, params, xs))
