@@ -29,7 +29,7 @@ except ImportError as e:  # pragma: no cover - PyTensor absent here
                       "functions in distributions_amd.<dist> do not") from e
 
 from . import _dispatch, _mv
-from ._lib import FN, NPARAMS
+from ._lib import FN, GRAD, NPARAMS
 
 
 def _out_dtype(inputs) -> str:
@@ -76,6 +76,74 @@ class M355Elemwise(Op):
     def infer_shape(self, fgraph, node, shapes):
         return [pt.broadcast_shape(*shapes, arrays_are_shapes=True)]
 
+    def L_op(self, inputs, outputs, output_grads):
+        """logpdf only: g_arg = sum over broadcast axes of (output gradient * d logpdf / d arg)."""
+        if self.fn != "logpdf" or self.dist not in GRAD:
+            raise NotImplementedError(f"no gradient kernel for {self.dist}.{self.fn}")
+        partials = M355LogpdfPartials(self.dist)(*inputs)
+        return [_sum_to(output_grads[0] * d, i) for d, i in zip(partials, inputs)]
+
+
+class M355LogpdfPartials(Op):
+    """[d logpdf/dx, d logpdf/dparam_0, ...] per element of the broadcast shape (m355_logpdf_grad): the
+    factors the L_op of the elementwise logpdf multiplies with the output gradient."""
+
+    __props__ = ("dist",)
+
+    def __init__(self, dist: str):
+        if dist not in GRAD:
+            raise NotImplementedError(f"{dist} has no gradient kernel")
+        self.dist = dist
+
+    def make_node(self, x, *params):
+        ins = [pt.as_tensor_variable(v) for v in (x, *params)]
+        shape = _broadcast_static_shape(ins)
+        dt = _out_dtype(ins)
+        return Apply(self, ins, [pt.tensor(dtype=dt, shape=shape) for _ in ins])
+
+    def perform(self, node, inputs, output_storage):
+        _total, grads = _dispatch.logpdf_grad(self.dist, *inputs, elementwise=True)
+        for st, g, out in zip(output_storage, grads, node.outputs):
+            st[0] = np.asarray(g, dtype=out.dtype)
+
+    def infer_shape(self, fgraph, node, shapes):
+        return [pt.broadcast_shape(*shapes, arrays_are_shapes=True)] * len(shapes)
+
+
+class M355SumLogpGrad(Op):
+    """Gradients of sum(logpdf) w.r.t. (x, *params), each in the shape of its argument, from one fused pass."""
+
+    __props__ = ("dist",)
+
+    def __init__(self, dist: str):
+        if dist not in GRAD:
+            raise NotImplementedError(f"{dist} has no gradient kernel")
+        self.dist = dist
+
+    def make_node(self, x, *params):
+        ins = [pt.as_tensor_variable(v) for v in (x, *params)]
+        outs = [pt.tensor(dtype=_out_dtype(ins), shape=i.type.shape) for i in ins]
+        return Apply(self, ins, outs)
+
+    def perform(self, node, inputs, output_storage):
+        _total, grads = _dispatch.logpdf_grad(self.dist, *inputs)
+        for st, g, out in zip(output_storage, grads, node.outputs):
+            st[0] = np.asarray(g, dtype=out.dtype)
+
+    def infer_shape(self, fgraph, node, shapes):
+        return list(shapes)
+
+
+def _sum_to(g, like):
+    """Sum `g` (broadcast shape) down to the shape of the variable `like` (Elemwise L_op convention)."""
+    lead = g.type.ndim - like.type.ndim
+    if lead:
+        g = g.sum(axis=tuple(range(lead)))
+    axes = [a for a in range(like.type.ndim) if like.type.shape[a] == 1 and g.type.shape[a] != 1]
+    if axes:
+        g = g.sum(axis=axes, keepdims=True)
+    return g
+
 
 class M355SumLogp(Op):
     """scalar = sum(<dist>.<fn>(x, *params)) in one fused pass (m355_sumlogp)."""
@@ -94,6 +162,12 @@ class M355SumLogp(Op):
 
     def infer_shape(self, fgraph, node, shapes):
         return [()]
+
+    def L_op(self, inputs, outputs, output_grads):
+        if self.fn != "logpdf" or self.dist not in GRAD:
+            raise NotImplementedError(f"no gradient kernel for sum of {self.dist}.{self.fn}")
+        grads = M355SumLogpGrad(self.dist)(*inputs)
+        return [output_grads[0] * g for g in grads]
 
 
 class M355MvLogpdf(Op):
