@@ -225,7 +225,7 @@ def _unbroadcast(t, shape, torch):
     return t.reshape(shape)
 
 
-def logpdf_grad(dist: str, x: Any, *params: Any, elementwise: bool = False):
+def logpdf_grad(dist: str, x: Any, *params: Any, elementwise: bool = False, x_grad: bool = True):
     """Value and gradient of sum(<dist>.logpdf(x, *params)) in one pass over x (m355_logpdf_grad; what
     pytensor.grad of the reference's graph gives).
 
@@ -233,7 +233,9 @@ def logpdf_grad(dist: str, x: Any, *params: Any, elementwise: bool = False):
     argument (scalar arguments get the summed partial straight from the kernel's reduction; array
     arguments get the per-element partials, summed over the axes they were broadcast along).
     elementwise=True: returns (total, [d logpdf/dx, d logpdf/dparam_0, ...]) per element of the
-    broadcast shape (the factors an Elemwise L_op multiplies with the output gradient)."""
+    broadcast shape (the factors an Elemwise L_op multiplies with the output gradient).
+    x_grad=False: x is data, its gradient is returned as None and, for an array x with scalar parameters,
+    never computed (the kernel then costs little more than the value alone)."""
     if len(params) != NPARAMS[dist]:
         raise TypeError(f"{dist}.logpdf takes {NPARAMS[dist]} parameters, got {len(params)}")
     if dist not in _lib.GRAD:
@@ -250,6 +252,7 @@ def logpdf_grad(dist: str, x: Any, *params: Any, elementwise: bool = False):
         ws_bytes = int(L.m355_sumlogp_workspace_bytes())
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=device)
         want = [elementwise or op.kind != "scalar" for op in pl.operands]
+        want[0] = want[0] and x_grad
         bufs = [torch.empty(pl.n, dtype=out_dt, device=device) if (w and pl.n) else None for w in want]
         dptrs = (ctypes.c_void_p * max(np_, 1))(*[b.data_ptr() if b is not None else None for b in bufs[1:]])
         ops, keep = _build_operands(pl, args, torch, device)
@@ -262,6 +265,9 @@ def logpdf_grad(dist: str, x: Any, *params: Any, elementwise: bool = False):
         del keep
         grads = []
         for j, (a, b) in enumerate(zip(args, bufs)):
+            if j == 0 and not x_grad:
+                grads.append(None)
+                continue
             if elementwise:
                 g = b.reshape(pl.shape) if b is not None else torch.zeros(pl.shape, dtype=out_dt, device=device)
             elif b is None and pl.operands[j].kind != "scalar":  # empty broadcast shape
@@ -274,7 +280,7 @@ def logpdf_grad(dist: str, x: Any, *params: Any, elementwise: bool = False):
     if _wants_torch(args):
         return sums[0].reshape(()), grads
     host = sums.cpu().numpy()
-    return float(host[0]), [g.cpu().numpy() for g in grads]
+    return float(host[0]), [g.cpu().numpy() if g is not None else None for g in grads]
 
 
 # ------------------------------------------------------------------------------------------- rvs

@@ -48,11 +48,11 @@ def export_grad(ns: dict, dist: str) -> None:
     pytensor.grad of its logpdf graph)."""
     sig = ", ".join(PARAMS[dist])
     loc: dict = {}
-    exec(f"def sum_logpdf_grad(x, {sig}):\n    return _g({dist!r}, x, {sig})\n"
+    exec(f"def sum_logpdf_grad(x, {sig}, x_grad=True):\n    return _g({dist!r}, x, {sig}, x_grad=x_grad)\n"
          f"def dlogpdf(x, {sig}):\n    return _g({dist!r}, x, {sig}, elementwise=True)[1]\n",
          {"_g": _logpdf_grad}, loc)  # noqa: S102
     loc["sum_logpdf_grad"].__doc__ = ("(sum(logpdf(x, ...)), [gradient w.r.t. x, w.r.t. each parameter]) in one pass; "
-                                      "every gradient has the shape of its argument.")
+                                      "every gradient has the shape of its argument (x_grad=False: x is data, its slot is None).")
     loc["dlogpdf"].__doc__ = "[d logpdf/dx, d logpdf/dparam_0, ...] per element of the broadcast shape."
     ns["sum_logpdf_grad"] = loc["sum_logpdf_grad"]
     ns["dlogpdf"] = loc["dlogpdf"]

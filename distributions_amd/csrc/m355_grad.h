@@ -461,8 +461,9 @@ template <class R, int... I> M355_DEV void grad_unpack(const R& r, double* out, 
   out[0] = r.v;
   ((out[1 + I] = r.template get<I>()), ...);
 }
-template <class G, class K> M355_DEV void grad_eval(double x, const K& k, double* out) {
-  const auto r = G::lp(Dual<1u>{x, {1.0}}, k);
+// XM = 1: x is a variable (d/dx computed); XM = 0: x is data only -- every x-partial disappears at compile time
+template <class G, unsigned XM = 1u, class K> M355_DEV void grad_eval(double x, const K& k, double* out) {
+  const auto r = G::lp(Dual<XM>{x, {1.0}}, k);
   grad_unpack(r, out, std::make_integer_sequence<int, 1 + G::NP>{});
 }
 

@@ -3,7 +3,8 @@
 //   k_grad_scalar   x full, contiguous and aligned, scalar parameters: the parameter-only part of the graph
 //                   (Grad<D>::pre: lgamma / digamma / logs of parameters and their partials) is evaluated once
 //                   per thread, then x is streamed as in k_scalar (16-byte non-temporal loads; dx written the
-//                   same way when requested).  8 B read (+ 8 B written with dx) per element.
+//                   same way when requested; without dx, x is data only and its partials are not even
+//                   compiled in).  8 B read (+ 8 B written with dx) per element.
 //   k_grad_generic  any broadcast layout: operands by (i / div) % mod, pre() per element, optional
 //                   per-element outputs for every partial (the caller reduces those over broadcast axes).
 // Both leave (2 + NP) partial sums per workgroup in `partials` ([slot][block]); k_grad_final adds them in a
@@ -62,8 +63,8 @@ __global__ __launch_bounds__(kBlock) void k_grad_scalar(const void* __restrict__
 #pragma unroll
     for (int u = 0; u < kUnroll; ++u) {
       double r0[S], r1[S];
-      grad_eval<G>(v[u][0], k, r0);
-      grad_eval<G>(v[u][1], k, r1);
+      grad_eval<G, WRITE_DX ? 1u : 0u>(v[u][0], k, r0);
+      grad_eval<G, WRITE_DX ? 1u : 0u>(v[u][1], k, r1);
 #pragma unroll
       for (int s = 0; s < S; ++s) acc[s] += r0[s] + r1[s];
       if constexpr (WRITE_DX) store2<false>(dx, odt, base + u * (kBlock * kVec), r0[1], r1[1]);
@@ -72,11 +73,12 @@ __global__ __launch_bounds__(kBlock) void k_grad_scalar(const void* __restrict__
   for (long long i = ntiles * kTile + (long long)blockIdx.x * kBlock + threadIdx.x; i < n;
        i += (long long)gridDim.x * kBlock) {
     double r[S];
-    grad_eval<G>(load1(x, xdt, i), k, r);
+    grad_eval<G, WRITE_DX ? 1u : 0u>(load1(x, xdt, i), k, r);
 #pragma unroll
     for (int s = 0; s < S; ++s) acc[s] += r[s];
     if constexpr (WRITE_DX) store1(dx, odt, i, r[1]);
   }
+  if constexpr (!WRITE_DX) acc[1] = kNaN;  // sum d/dx is not computed on this path (see include/m355_dist.h)
   block_reduce_multi<S>(acc, partials, gridDim.x);
 }
 

@@ -150,6 +150,8 @@ int m355_sumlogp(int dist, int fn, int64_t n, const m355_operand* x, int nparams
  * is what the L_op of a custom Op over m355_elemwise / m355_sumlogp calls.
  *   sums (device, 2 + nparams doubles): [sum logpdf, sum d/dx, sum d/dparam_0, ...] over the n elements of
  *        the broadcast of (x, params) -- for scalar parameters sums[2 + j] is d(sum logpdf)/d(param_j).
+ *        sums[1] is NaN (not computed) when x is a full contiguous array and dx is NULL: a caller that does not
+ *        ask for d/dx of an array x gets the parameter gradients at the cost of the value alone.
  *   dx (device, n elements of out_dtype, or NULL): d logpdf / dx per element.
  *   dparams (host array of nparams device pointers, or NULL; entries may be NULL): d logpdf / d param_j
  *        per element of the broadcast shape (the caller reduces over the axes the parameter was broadcast

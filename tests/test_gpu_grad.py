@@ -49,6 +49,11 @@ def test_grad_dense_parity(gpu, name, sp_dist, params, sp_params, support, kw):
         assert abs(float(g[1 + j]) - math.fsum(e)) <= 1e-12 * max(1.0, float(scale.sum())), (name, j)
     t2, g2 = m.sum_logpdf_grad(xi, *params)
     assert t2 == total and all(np.array_equal(a, b) for a, b in zip(g, g2))  # deterministic
+    # x as data only (the x-partials are compiled out): same value and parameter gradients
+    t3, g3 = m.sum_logpdf_grad(xi, *params, x_grad=False)
+    assert g3[0] is None and abs(t3 - total) <= 1e-12 * max(1.0, float(np.abs(val[fin]).sum()))
+    for j in range(len(params)):
+        assert abs(float(g3[1 + j]) - float(g[1 + j])) <= 1e-12 * max(1.0, float(scale.sum())), (name, j)
 
 
 def test_grad_layouts(gpu):
