@@ -209,7 +209,8 @@ int m355_rvs(int dist, int out_dtype, int64_t n, int nparams, const m355_operand
   if (nparams != np) return fail(M355_ERR_INVALID, "distribution %d takes %d parameters, got %d", dist, np, nparams);
   if (n < 0) return fail(M355_ERR_INVALID, "n must be >= 0");
   if (params == nullptr) return fail(M355_ERR_INVALID, "params must not be NULL");
-  const bool discrete = dist == M355_POISSON || dist == M355_BINOMIAL || dist >= M355_BERNOULLI;
+  const bool discrete = dist == M355_POISSON || dist == M355_BINOMIAL ||
+                        (dist >= M355_BERNOULLI && dist <= M355_ZI_NEGATIVEBINOMIAL);
   if (out_dtype != M355_F64 && out_dtype != M355_F32 && !(discrete && out_dtype == M355_I64))
     return fail(M355_ERR_INVALID, "out_dtype %d not valid for distribution %d", out_dtype, dist);
   if (n == 0) return M355_OK;

@@ -39,4 +39,8 @@
   X(M355_HYPERGEOMETRIC, hypergeometric, 3) \
   X(M355_ZI_POISSON, zi_poisson, 2) \
   X(M355_ZI_BINOMIAL, zi_binomial, 3) \
-  X(M355_ZI_NEGATIVEBINOMIAL, zi_negativebinomial, 3)
+  X(M355_ZI_NEGATIVEBINOMIAL, zi_negativebinomial, 3) \
+  X(M355_WALD, wald, 2) \
+  X(M355_EXGAUSSIAN, exgaussian, 3) \
+  X(M355_TRUNCATEDNORMAL, truncatednormal, 4) \
+  X(M355_SKEW_STUDENTT, skew_studentt, 4)

@@ -21,7 +21,9 @@
 #include <hip/hip_runtime.h>
 
 #include "m355_dist_list.h"
-#include "m355_dists3.h"
+#include <type_traits>
+
+#include "m355_dists4.h"
 
 namespace m355 {
 
@@ -263,6 +265,11 @@ __global__ __launch_bounds__(kBlock) void k_generic(GenericOps ops, void* __rest
   }
 }
 
+// Dist<D>::kDeviceDerive: derive() needs device-only functions, so scalar parameters go through k_periodic
+// with a one-entry table (derived once per workgroup) instead of being derived on the host.
+template <class T, class = void> struct device_derive : std::false_type {};
+template <class T> struct device_derive<T, std::void_t<decltype(T::kDeviceDerive)>> : std::true_type {};
+
 inline bool aligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; }
 
 // Host-side selection of the kernel for one (dist, fn); returns a hipError_t as int.
@@ -297,19 +304,23 @@ template <int D, int FN, bool REDUCE> int launch_fn(const LaunchArgs& a) {
     blocks = (int)(want < 1 ? 1 : (want > cap ? cap : want));
   }
   if (REDUCE && a.nblocks_out) *a.nblocks_out = blocks;
-  if (vec_ok && all_scalar) {
-    // parameter-only constants once, on the host; they reach the kernel as arguments (SGPRs)
-    const double pp[kMaxParams] = {a.p[0].scalar, a.p[1].scalar, a.p[2].scalar, a.p[3].scalar};
-    const typename DD::K k = DD::derive(pp);
-    if (f64io) {
-      if constexpr (kFastIO)
-        hipLaunchKernelGGL((k_scalar<D, FN, REDUCE, true>), dim3(blocks), dim3(kBlock), 0, a.stream,
-                           a.x.ptr, a.x.dtype, a.out, a.out_dtype, n, k, a.partials);
-    } else {
-      hipLaunchKernelGGL((k_scalar<D, FN, REDUCE, false>), dim3(blocks), dim3(kBlock), 0, a.stream, a.x.ptr,
-                         a.x.dtype, a.out, a.out_dtype, n, k, a.partials);
+  constexpr bool kDevDerive = device_derive<DD>::value;
+  if (kDevDerive && all_scalar) P = 1;
+  if (vec_ok && all_scalar && !kDevDerive) {
+    if constexpr (!kDevDerive) {
+      // parameter-only constants once, on the host; they reach the kernel as arguments (SGPRs)
+      const double pp[kMaxParams] = {a.p[0].scalar, a.p[1].scalar, a.p[2].scalar, a.p[3].scalar};
+      const typename DD::K k = DD::derive(pp);
+      if (f64io) {
+        if constexpr (kFastIO)
+          hipLaunchKernelGGL((k_scalar<D, FN, REDUCE, true>), dim3(blocks), dim3(kBlock), 0, a.stream,
+                             a.x.ptr, a.x.dtype, a.out, a.out_dtype, n, k, a.partials);
+      } else {
+        hipLaunchKernelGGL((k_scalar<D, FN, REDUCE, false>), dim3(blocks), dim3(kBlock), 0, a.stream, a.x.ptr,
+                           a.x.dtype, a.out, a.out_dtype, n, k, a.partials);
+      }
     }
-  } else if (vec_ok && periodic_ok) {
+  } else if (vec_ok && (periodic_ok || all_scalar)) {
     PeriodicParams pa;
     for (int q = 0; q < kMaxParams; ++q) {
       pa.ptr[q] = (q < DD::NP) ? static_cast<const double*>(a.p[q].ptr) : nullptr;

@@ -9,7 +9,7 @@
 // inversion (mu < 10) or PTRS (Hoermann 1993), binomial by sequential inversion (n*min(p,q) < 10)
 // or BTRS (Hoermann 1993).  Rejection loops run per lane with a bounded attempt count.
 #pragma once
-#include "m355_special.h"
+#include "m355_dists4.h"
 
 namespace m355 {
 
@@ -386,6 +386,28 @@ template <int D> M355_DEV double sample_one(unsigned long long idx, unsigned lon
     else if constexpr (D == M355_ZI_BINOMIAL) base = sample_binomial(st, p[1], p[2]);
     else base = sample_poisson(st, sample_std_gamma(st, p[1]) * ((1.0 - p[2]) / p[2]));
     return (u1 < p[0]) ? base : 0.0;
+  } else if constexpr (D == M355_WALD) {  // wald.py:67-68: Michael-Schucany-Haas (numpy's random_wald)
+    double u1, u2, z0, z1;
+    next_pair(st, u1, u2);
+    normal_pair(u1, u2, z0, z1);
+    double u3, u4;
+    next_pair(st, u3, u4);
+    const double mean = p[0], scale = p[1];
+    const double y = mean * z0 * z0;
+    const double x = mean + mean / (2.0 * scale) * (y - fsqrt(4.0 * scale * y + y * y));
+    return (u3 <= mean / (mean + x)) ? x : mean * mean / x;
+  } else if constexpr (D == M355_EXGAUSSIAN) {  // exgaussian.py:70-73: normal(mu, sigma) + exponential(scale nu)
+    double u1, u2, z0, z1;
+    next_pair(st, u1, u2);
+    normal_pair(u1, u2, z0, z1);
+    double u3, u4;
+    next_pair(st, u3, u4);
+    return (p[0] + p[1] * z0) + (-flog(u3) * p[2]);
+  } else if constexpr (D == M355_TRUNCATEDNORMAL || D == M355_SKEW_STUDENTT) {
+    // truncatednormal.py:273-275, skew_studentt.py:164-166: ppf(uniform(0, 1))
+    double u1, u2;
+    next_pair(st, u1, u2);
+    return Dist<D>::template eval<M355_PPF>(u1, Dist<D>::derive(p));
   } else if constexpr (D == M355_INVERSEGAMMA) {  // inversegamma.py:69-70: 1 / Gamma(alpha, rate beta)
     return p[1] / sample_std_gamma(st, p[0]);
   } else if constexpr (D == M355_CHISQUARED) {  // chisquared.py:59-60

@@ -41,7 +41,18 @@ M355_DEV double expm1_(double x) { return std::expm1(x); }
 M355_DEV double lgamma_(double x) { return std::lgamma(x); }
 M355_DEV double erf_(double x) { return std::erf(x); }
 M355_DEV double erfc_(double x) { return std::erfc(x); }
-M355_DEV double erfcx_(double x) { return kNaN; }   // device libm only; not host-tested
+// host stand-in for the device libm's erfcx (CPU unit tests only): erfc(x) exp(x^2) with x^2 split exactly,
+// the asymptotic series beyond the range where erfc underflows
+inline double erfcx_(double x) {
+  if (!(x == x)) return x;
+  if (x < 0.0) return (x < -26.7) ? kInf : 2.0 * std::exp(x * x) - erfcx_(-x);
+  if (x > 25.0) {
+    const double r = 1.0 / (x * x);
+    return 0.56418958354775628695 / x * (1.0 + r * (-0.5 + r * (0.75 + r * (-1.875 + r * 6.5625))));
+  }
+  const double hi = x * x, lo = std::fma(x, x, -hi);
+  return std::erfc(x) * std::exp(hi) * (1.0 + lo);
+}
 M355_DEV double erfinv_(double x) { return kNaN; }  // device libm only; not host-tested
 M355_DEV double sqrt_(double x) { return std::sqrt(x); }
 M355_DEV double floor_(double x) { return std::floor(x); }
@@ -481,6 +492,7 @@ M355_DEV_HEAVY double betaincinv_(double a, double b, double p, double lbeta) {
   if (!(a > 0.0) || !(b > 0.0) || !(p >= 0.0) || !(p <= 1.0)) return kNaN;
   if (p == 0.0) return 0.0;
   if (p == 1.0) return 1.0;
+  if (a == b && p == 0.5) return 0.5;  // the symmetric median, exactly (skew_studentt.ppf(0.5; a = b) must be mu)
   const bool rep_y = p > betainc_xy(a, b, 0.5, 0.5, lbeta);
   // Equation: I_x(a,b) = p for p <= 1/2, else I_y(b,a) = 1-p (exact), so that the small tail
   // keeps full relative accuracy; betainc_xy takes x and y separately, so either equation can

@@ -84,7 +84,11 @@ enum m355_dist {
   M355_ZI_POISSON = 35,                /* zi_poisson.py */
   M355_ZI_BINOMIAL = 36,               /* zi_binomial.py */
   M355_ZI_NEGATIVEBINOMIAL = 37,       /* zi_negativebinomial.py */
-  M355_DIST_COUNT = 38
+  M355_WALD = 38,                      /* wald.py (ppf: find_ppf, optimization.py:10-32) */
+  M355_EXGAUSSIAN = 39,                /* exgaussian.py (ppf: find_ppf) */
+  M355_TRUNCATEDNORMAL = 40,           /* truncatednormal.py */
+  M355_SKEW_STUDENTT = 41,             /* skew_studentt.py */
+  M355_DIST_COUNT = 42
 };
 
 /* function ids: the reference function of that module */

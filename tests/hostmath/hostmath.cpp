@@ -3,7 +3,7 @@
 // GPU is attached.  The hardware seeds (v_rcp_f64, v_frexp_*) and the device libm (lgamma, exp,
 // erfc) are replaced by host equivalents, so this is NOT the parity test: parity is tests -m gpu.
 #include "../../distributions_amd/csrc/m355_dist_list.h"
-#include "../../distributions_amd/csrc/m355_dists3.h"
+#include "../../distributions_amd/csrc/m355_dists4.h"
 #include "../../distributions_amd/csrc/m355_grad.h"
 
 using namespace m355;

@@ -285,6 +285,10 @@ FAMILY_RVS = [
     ("scaledinversechisquared", (10.0, 2.0), lambda: stats.invgamma(a=5.0, scale=10.0)),
     ("halfstudentt", (1.0, 3.5), lambda: stats.halfcauchy(scale=3.5)),
     ("betascaled", (2.0, 5.0, -1.0, 3.0), lambda: stats.beta(a=2.0, b=5.0, loc=-1.0, scale=4.0)),
+    ("wald", (2.0, 10.0), lambda: stats.invgauss(mu=0.2, scale=10.0)),
+    ("exgaussian", (1.0, 3.0, 3.0), lambda: stats.exponnorm(K=1.0, loc=1.0, scale=3.0)),
+    ("truncatednormal", (2.0, 1.5, -1.0, 5.0), lambda: stats.truncnorm(a=-2.0, b=2.0, loc=2.0, scale=1.5)),
+    ("skew_studentt", (8.0, 4.0, 0.0, 1.0), lambda: stats.jf_skew_t(a=8.0, b=4.0, loc=0.0, scale=1.0)),
 ]
 
 
