@@ -57,6 +57,8 @@ PARAMS = {
     "exgaussian": ('mu', 'sigma', 'nu'),
     "truncatednormal": ('mu', 'sigma', 'lower', 'upper'),
     "skew_studentt": ('a', 'b', 'mu', 'sigma'),
+    "skewnormal": ('mu', 'sigma', 'alpha'),
+    "vonmises": ('mu', 'kappa'),
 }
 DIST = {name: i for i, name in enumerate(PARAMS)}
 NPARAMS = {name: len(ps) for name, ps in PARAMS.items()}

@@ -1,0 +1,4 @@
+// Kernel instantiations for vonmises.py (see m355_elemwise.h).
+#include "m355_elemwise.h"
+
+M355_DEFINE_LAUNCH(M355_VONMISES, vonmises)

@@ -403,6 +403,45 @@ template <int D> M355_DEV double sample_one(unsigned long long idx, unsigned lon
     double u3, u4;
     next_pair(st, u3, u4);
     return (p[0] + p[1] * z0) + (-flog(u3) * p[2]);
+  } else if constexpr (D == M355_SKEWNORMAL) {  // skewnormal.py:87-92
+    double u1, u2, z0, z1;
+    next_pair(st, u1, u2);
+    normal_pair(u1, u2, z0, z1);
+    const double d = p[2] / fsqrt(1.0 + p[2] * p[2]);
+    const double w = d * z0 + z1 * fsqrt(1.0 - d * d);
+    const double sg = z0 > 0.0 ? 1.0 : (z0 < 0.0 ? -1.0 : 0.0);
+    return sg * w * p[1] + p[0];
+  } else if constexpr (D == M355_VONMISES) {  // vonmises.py:49-50: Best & Fisher (numpy's random_vonmises)
+    const double mu = p[0], kappa = p[1];
+    double u1, u2;
+    if (kappa < 1e-8) {
+      next_pair(st, u1, u2);
+      return kPi * (2.0 * u1 - 1.0);
+    }
+    double s;
+    if (kappa < 1e-5) {
+      s = 1.0 / kappa + kappa;
+    } else {
+      const double r = 1.0 + fsqrt(1.0 + 4.0 * kappa * kappa);
+      const double rho = (r - fsqrt(2.0 * r)) / (2.0 * kappa);
+      s = (1.0 + rho * rho) / (2.0 * rho);
+    }
+    double w = 1.0;
+    for (int it = 0; it < kMaxAttempts; ++it) {
+      next_pair(st, u1, u2);
+      const double z = ::cos(kPi * u1);
+      w = (1.0 + s * z) / (s + z);
+      const double y = kappa * (s - w);
+      if ((y * (2.0 - y) - u2 >= 0.0) || (flog(y / u2) + 1.0 - y >= 0.0)) break;
+    }
+    next_pair(st, u1, u2);
+    double res = ::acos(w);
+    if (u1 < 0.5) res = -res;
+    res += mu;
+    const bool neg = res < 0.0;
+    double m = __builtin_fabs(res);
+    m = ::fmod(m + kPi, 2.0 * kPi) - kPi;
+    return neg ? -m : m;
   } else if constexpr (D == M355_TRUNCATEDNORMAL || D == M355_SKEW_STUDENTT) {
     // truncatednormal.py:273-275, skew_studentt.py:164-166: ppf(uniform(0, 1))
     double u1, u2;

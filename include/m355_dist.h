@@ -88,7 +88,9 @@ enum m355_dist {
   M355_EXGAUSSIAN = 39,                /* exgaussian.py (ppf: find_ppf) */
   M355_TRUNCATEDNORMAL = 40,           /* truncatednormal.py */
   M355_SKEW_STUDENTT = 41,             /* skew_studentt.py */
-  M355_DIST_COUNT = 42
+  M355_SKEWNORMAL = 42,                /* skewnormal.py (cdf through Owen's T; ppf: find_ppf) */
+  M355_VONMISES = 43,                  /* vonmises.py (cdf: helper.py:337-372; ppf: find_ppf) */
+  M355_DIST_COUNT = 44
 };
 
 /* function ids: the reference function of that module */

@@ -1,7 +1,7 @@
 """CPU oracle for the solver families -- TEST INFRASTRUCTURE ONLY.
 
 NumPy/SciPy float64 restatement, line by line, of the reference modules wald.py, exgaussian.py,
-truncatednormal.py, skew_studentt.py and of `find_ppf` (optimization.py:10-32); citations are
+truncatednormal.py, skew_studentt.py, skewnormal.py, vonmises.py (+ helper.py:337-372) and of `find_ppf` (optimization.py:10-32); citations are
 file:line of /root/reference/pytensor_distributions.  Pinned against the reference's own SciPy
 grids (tests/test_wald.py:10-19, test_exgaussian.py:10-18, test_truncatednormal.py:10-26,
 test_skew_studentt.py:11-21) by tests/test_oracle_pinning.py.  Only tests/,
@@ -281,6 +281,115 @@ def skew_studentt_ppf(q, a, b, mu, sigma):  # skew_studentt.py:150-157
 @_wrap
 def skew_studentt_isf(q, a, b, mu, sigma):  # skew_studentt.py:160-161
     return skew_studentt_ppf(1 - q, a, b, mu, sigma)
+
+
+# -------------------------------------------------------------------------------- skewnormal.py
+def _skewnormal_mean(mu, sigma, alpha):  # skewnormal.py:8-10
+    return mu + sigma * np.sqrt(2 / np.pi) * alpha / np.sqrt(1 + alpha**2)
+
+
+@_wrap
+def skewnormal_cdf(x, mu, sigma, alpha):  # skewnormal.py:61-62
+    return 0.5 * (1 + sp.erf((x - mu) / (sigma * 2**0.5))) - 2 * sp.owens_t((x - mu) / sigma, alpha)
+
+
+@_wrap
+def skewnormal_logcdf(x, mu, sigma, alpha):  # skewnormal.py:65-66
+    return np.log(skewnormal_cdf(x, mu, sigma, alpha))
+
+
+@_wrap
+def skewnormal_logpdf(x, mu, sigma, alpha):  # skewnormal.py:95-100
+    tau = 1.0 / (sigma**2)
+    return (np.log(1 + sp.erf(((x - mu) * np.sqrt(tau) * alpha) / np.sqrt(2)))
+            + (-tau * (x - mu) ** 2 + np.log(tau / np.pi / 2.0)) / 2.0)
+
+
+@_wrap
+def skewnormal_pdf(x, mu, sigma, alpha):  # skewnormal.py:73-74
+    return np.exp(skewnormal_logpdf(x, mu, sigma, alpha))
+
+
+@_wrap
+def skewnormal_sf(x, mu, sigma, alpha):  # skewnormal.py:83-84
+    return 1 - skewnormal_cdf(x, mu, sigma, alpha)
+
+
+@_wrap
+def skewnormal_logsf(x, mu, sigma, alpha):  # skewnormal.py:103-104
+    return log1mexp(skewnormal_logcdf(x, mu, sigma, alpha))
+
+
+@_wrap
+def skewnormal_ppf(q, mu, sigma, alpha):  # skewnormal.py:77-80
+    q, mu, sigma, alpha = np.broadcast_arrays(q, mu, sigma, alpha)
+    return find_ppf(q, _skewnormal_mean(mu, sigma, alpha), -inf, inf, skewnormal_cdf, skewnormal_pdf, mu, sigma, alpha)
+
+
+@_wrap
+def skewnormal_isf(q, mu, sigma, alpha):  # skewnormal.py:69-70
+    return skewnormal_ppf(1 - q, mu, sigma, alpha)
+
+
+# ---------------------------------------------------------------------------------- vonmises.py
+def von_mises_cdf(x, mu, kappa):
+    """helper.py:337-372 (series in ive ratios for kappa < 50, normal approximation above)."""
+    x, mu, kappa = np.broadcast_arrays(*_f(x, mu, kappa))
+    xc = x - mu
+    ix = np.round(xc / (2 * np.pi))
+    xw = xc - ix * 2 * np.pi
+    p = np.clip(np.round(1 + 28.0 + 0.5 * kappa - 100.0 / (kappa + 5.0)), 5, 50).astype(np.int32)
+    n = np.arange(1, 51, dtype=_F).reshape((-1,) + (1,) * x.ndim)
+    with _quiet():
+        ratio = sp.ive(n, kappa) / sp.ive(0, kappa)
+        terms = ratio * np.sin(n * xw) / n
+        series = np.sum(sw(n <= p, terms, 0.0), axis=0)
+        cdf_series = np.clip(0.5 + xw / (2 * np.pi) + series / np.pi, 0.0, 1.0)
+        b = np.sqrt(2 / np.pi) / sp.ive(0.0, kappa)
+        z = b * np.sin(xw / 2.0)
+        cdf_norm = 0.5 * (1.0 + sp.erf(z / np.sqrt(2.0)))
+    return sw(kappa < 50.0, cdf_series, cdf_norm) + ix
+
+
+@_wrap
+def vonmises_logpdf(x, mu, kappa):  # vonmises.py:45-46
+    return kappa * (np.cos(x - mu) - 1) - np.log(2 * np.pi) - np.log(sp.ive(0, kappa))
+
+
+@_wrap
+def vonmises_pdf(x, mu, kappa):  # vonmises.py:41-42
+    return np.exp(vonmises_logpdf(x, mu, kappa))
+
+
+@_wrap
+def vonmises_cdf(x, mu, kappa):  # vonmises.py:53-54
+    return von_mises_cdf(x, mu, kappa)
+
+
+@_wrap
+def vonmises_logcdf(x, mu, kappa):  # vonmises.py:57-58
+    return np.log(von_mises_cdf(x, mu, kappa))
+
+
+@_wrap
+def vonmises_sf(x, mu, kappa):  # vonmises.py:61-62
+    return 1.0 - von_mises_cdf(x, mu, kappa)
+
+
+@_wrap
+def vonmises_logsf(x, mu, kappa):  # vonmises.py:65-66
+    return np.log1p(-von_mises_cdf(x, mu, kappa))
+
+
+@_wrap
+def vonmises_ppf(q, mu, kappa):  # vonmises.py:73-74 (x0 = mean = mu)
+    q, mu, kappa = np.broadcast_arrays(q, mu, kappa)
+    return find_ppf(q, mu, -inf, inf, von_mises_cdf, vonmises_pdf, mu, kappa)
+
+
+@_wrap
+def vonmises_isf(q, mu, kappa):  # vonmises.py:69-70
+    return vonmises_ppf(1 - q, mu, kappa)
 
 
 SOLVER_TABLE = {k: v for k, v in list(globals().items())

@@ -134,6 +134,10 @@ def solver_grids():
                             (6.0, 3.0, -1.0, 2.0)]:
         g.append(("skew_studentt", stats.jf_skew_t, [a, b, mu, sigma], {"a": a, "b": b, "loc": mu, "scale": sigma},
                   (-inf, inf), {"rtols": {"pdf": 1e-5, "logpdf": 1e-5, "cdf": 1e-5}}))
+    for mu, sigma, alpha in [(0.5, 1.0, -2.0), (0.0, 1.0, 10.0), (0.0, 1.0, -10.0)]:  # tests/test_skewnormal.py:10-17
+        g.append(("skewnormal", stats.skewnorm, [mu, sigma, alpha], {"a": alpha, "loc": mu, "scale": sigma}, (-inf, inf), {}))
+    for mu, kappa in [(0.5, 1.0), (1.5, 2.0), (1.0, 60.0)]:  # tests/test_vonmises.py:11-18 (skip_isf :32)
+        g.append(("vonmises", stats.vonmises, [mu, kappa], {"loc": mu, "kappa": kappa}, (-np.pi, np.pi), {"skip_isf": True}))
     return g
 
 
@@ -322,7 +326,7 @@ def ppf_unpinned(name, fn, pts):
     return np.zeros(np.shape(pts), dtype=bool)
 
 
-FIND_PPF_FAMILIES = ("wald", "exgaussian")
+FIND_PPF_FAMILIES = ("wald", "exgaussian", "skewnormal", "vonmises")
 
 
 def grad_close(got, exp, info, tol=1e-12):

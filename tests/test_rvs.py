@@ -289,6 +289,8 @@ FAMILY_RVS = [
     ("exgaussian", (1.0, 3.0, 3.0), lambda: stats.exponnorm(K=1.0, loc=1.0, scale=3.0)),
     ("truncatednormal", (2.0, 1.5, -1.0, 5.0), lambda: stats.truncnorm(a=-2.0, b=2.0, loc=2.0, scale=1.5)),
     ("skew_studentt", (8.0, 4.0, 0.0, 1.0), lambda: stats.jf_skew_t(a=8.0, b=4.0, loc=0.0, scale=1.0)),
+    ("skewnormal", (0.5, 1.0, -2.0), lambda: stats.skewnorm(a=-2.0, loc=0.5, scale=1.0)),
+    ("vonmises", (0.5, 2.0), lambda: stats.vonmises(kappa=2.0, loc=0.5)),
 ]
 
 
@@ -303,7 +305,11 @@ def test_gpu_rvs_families(gpu, name, params, make):
     n = 200_000
     x = m.rvs(*params, size=n, random_state=21)
     assert x.shape == (n,) and x.dtype == np.float64 and np.all(np.isfinite(x))
-    assert stats.kstest(x, make().cdf).pvalue > 1e-3
+    xk = x
+    if name == "vonmises":  # draws are wrapped to [-pi, pi] (numpy's sampler); SciPy's cdf lives on [loc - pi, loc + pi]
+        assert np.all(np.abs(x) <= np.pi)
+        xk = np.mod(x - params[0] + np.pi, 2 * np.pi) - np.pi + params[0]
+    assert stats.kstest(xk, make().cdf).pvalue > 1e-3
     assert np.array_equal(x, m.rvs(*params, size=n, random_state=21))
     h = 77_777
     assert np.array_equal(x, np.concatenate([m.rvs(*params, size=h, random_state=(21, 0)),
