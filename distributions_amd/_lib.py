@@ -59,6 +59,7 @@ PARAMS = {
     "skew_studentt": ('a', 'b', 'mu', 'sigma'),
     "skewnormal": ('mu', 'sigma', 'alpha'),
     "vonmises": ('mu', 'kappa'),
+    "rice": ('nu', 'sigma'),
 }
 DIST = {name: i for i, name in enumerate(PARAMS)}
 NPARAMS = {name: len(ps) for name, ps in PARAMS.items()}

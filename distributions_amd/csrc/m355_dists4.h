@@ -392,4 +392,133 @@ template <> struct Dist<M355_VONMISES> {
   }
 };
 
+// ----------------------------------------------------------------------------------------- rice
+// Exponentially scaled modified Bessel functions I_0, I_1 (pt.ive): ascending series below 20 (all terms
+// positive), Hankel's asymptotic series above (terms fall to e^{-2x} < 1e-17 before they grow).
+M355_DEV_HEAVY double ive01_(int order, double x) {
+  if (!(x == x)) return kNaN;
+  const double ax = __builtin_fabs(x);
+  double r;
+  if (ax < 20.0) {
+    const double q = 0.25 * ax * ax;
+    double term = (order == 0) ? 1.0 : 0.5 * ax, s = term;
+    for (int k = 1; k < 200; ++k) {
+      term *= q / ((double)k * (double)(k + order));
+      s += term;
+      if (term < 1e-17 * s) break;
+    }
+    r = s * exp_(-ax);
+  } else {
+    const double mu = (order == 0) ? 0.0 : 4.0;
+    double term = 1.0, s = 1.0;
+    for (int k = 1; k < 60; ++k) {
+      const double f = (2.0 * k - 1.0);
+      const double t = -term * (mu - f * f) / (8.0 * ax * k);
+      if (!(__builtin_fabs(t) < __builtin_fabs(term))) break;
+      term = t;
+      s += t;
+      if (__builtin_fabs(t) < 1e-17 * __builtin_fabs(s)) break;
+    }
+    r = s / sqrt_(2.0 * kPi * ax);
+  }
+  return (order == 1 && x < 0.0) ? -r : r;
+}
+
+// ncx2_cdf(x, df = 2, nc) of helper.py:449-512: sum_{j<800} w_j P(j + 1, x/2), w_j = Poisson(j; nc/2) (clipped in
+// log space to +-700).  With t_i = e^{-hx} hx^i / i! the regularised P(j + 1, hx) is sum_{i > j} t_i, so the
+// double sum is sum_{i >= 1} t_i W_{min(i-1, 799)} with the running W_m = sum_{j <= m} w_j: one forward pass,
+// every term positive (no cancellation for small x).
+M355_DEV_HEAVY double ncx2_cdf_df2(double x, double nc) {
+  if (!(x == x) || !(nc == nc)) return kNaN;
+  if (!(nc < 1000.0)) {  // normal approximation, helper.py:505-509
+    const double sd = sqrt_(2.0 * (2.0 + 2.0 * nc));
+    return 0.5 * (1.0 + erf_((x - (2.0 + nc)) / (sd * kSqrt2)));
+  }
+  const double hnc = 0.5 * nc, hx = 0.5 * x;
+  if (!(hnc > 0.0)) return kNaN;  // 0 * log(0) in the reference's log-weights
+  if (!(hx > 0.0)) return hx == 0.0 ? 0.0 : kNaN;
+  const double kMinW = 9.8596765437597708e-305;  // exp(-700): the reference's clip
+  // Poisson weights forward from w_0 = exp(-hnc) (hnc < 500: no underflow)
+  double w = exp_(-hnc);
+  double W = w < kMinW ? kMinW : w;  // W_0
+  int j = 0;                         // W holds W_j
+  if (hx == kInf) return kNaN;
+  // unnormalised Poisson terms u_i = c hx^i / i! by forward recurrence from i0 (terms below it are < e^-700 of the
+  // mode), normalised at the end by Z = sum_i u_i: the rounding drift of the recurrence is common to S and Z
+  long long i0 = 0;
+  if (hx > 600.0) {
+    const double lo = hx - 40.0 * sqrt_(hx);
+    if (lo > 1.0) i0 = (long long)lo;
+  }
+  auto advance_W = [&](long long upto) {  // make W = W_{min(upto, 799)}
+    const int target = (int)(upto < 799 ? upto : 799);
+    while (j < target) {
+      ++j;
+      w *= hnc / (double)j;
+      W += (w < kMinW ? kMinW : w);
+    }
+  };
+  double u = 1.0, S = 0.0, Z = 0.0;
+  const long long imax = i0 + 8000;
+  for (long long i = i0; i < imax; ++i) {
+    Z += u;
+    if (i >= 1) {
+      advance_W(i - 1);
+      S += u * W;
+    }
+    u *= hx / (double)(i + 1);
+    if (u > 1e200) {
+      u *= 1e-200;
+      S *= 1e-200;
+      Z *= 1e-200;
+    }
+    if ((double)i > hx && u < 1e-19 * Z) break;
+  }
+  S = S / Z;
+  return S;
+}
+
+template <> struct Dist<M355_RICE> {
+  static constexpr int NP = 2;
+  static constexpr bool kDeviceDerive = true;  // the Bessel series of the mean use the device exp
+  struct K { double nu, sigma, sigma2, c, a, nc, mean; };  // c = -2 log sigma - nu^2/(2 sigma^2); a = nu/sigma
+  static M355_DEV K derive(const double* p) {
+    K k;
+    k.nu = p[0];
+    k.sigma = p[1];
+    k.sigma2 = p[1] * p[1];
+    k.c = -2.0 * flog(p[1]);
+    k.a = p[0] / p[1];
+    k.nc = k.a * k.a;
+    const double q = (p[0] * p[0]) / (2.0 * k.sigma2);  // rice.py:13-28
+    k.mean = p[1] * sqrt_(kPi / 2.0) * ((1.0 + q) * ive01_(0, q / 2.0) + q * ive01_(1, q / 2.0));
+    return k;
+  }
+  static M355_DEV double logpdf(double x, const K& k) {  // rice.py:65-78
+    if (x <= 0.0) return -kInf;
+    if (x == kInf) return kNaN;
+    const double z = x * k.nu / k.sigma2;
+    return (((flog(x) + k.c) - (x * x + k.nu * k.nu) / (2.0 * k.sigma2)) + flog(ive01_(0, z))) + z;
+  }
+  static M355_DEV double pdf(double x, const K& k) { return exp_(logpdf(x, k)); }  // rice.py:61-62
+  static M355_DEV double cdf(double x, const K& k) {  // rice.py:81-83, helper.py:515-539
+    const double b = x / k.sigma;
+    const double prob = (b <= 0.0) ? 0.0 : ncx2_cdf_df2(b * b, k.nc);
+    return cdf_bounds(prob, x, 0.0, kInf);
+  }
+  template <int FN> static M355_DEV double eval(double x, const K& k) {
+    if constexpr (FN == M355_LOGPDF) return logpdf(x, k);
+    if constexpr (FN == M355_PDF) return pdf(x, k);
+    if constexpr (FN == M355_CDF) return cdf(x, k);
+    if constexpr (FN == M355_LOGCDF) return (x <= 0.0) ? -kInf : flog(cdf(x, k));  // rice.py:86-91
+    if constexpr (FN == M355_SF) return 1.0 - cdf(x, k);                            // rice.py:94-95
+    if constexpr (FN == M355_LOGSF) return flog(1.0 - cdf(x, k));                   // rice.py:98-99
+    if constexpr (FN == M355_PPF || FN == M355_ISF) {                              // rice.py:102-107
+      const double q = (FN == M355_ISF) ? 1.0 - x : x;
+      return find_ppf(q, k.mean, 0.0, kInf, [&](double v) { return cdf(v, k); }, [&](double v) { return pdf(v, k); });
+    }
+    return kNaN;
+  }
+};
+
 }  // namespace m355

@@ -403,6 +403,12 @@ template <int D> M355_DEV double sample_one(unsigned long long idx, unsigned lon
     double u3, u4;
     next_pair(st, u3, u4);
     return (p[0] + p[1] * z0) + (-flog(u3) * p[2]);
+  } else if constexpr (D == M355_RICE) {  // rice.py:110-113: |(nu + sigma z0, sigma z1)|
+    double u1, u2, z0, z1;
+    next_pair(st, u1, u2);
+    normal_pair(u1, u2, z0, z1);
+    const double a = p[0] + p[1] * z0, b = p[1] * z1;
+    return fsqrt(a * a + b * b);
   } else if constexpr (D == M355_SKEWNORMAL) {  // skewnormal.py:87-92
     double u1, u2, z0, z1;
     next_pair(st, u1, u2);

@@ -90,7 +90,8 @@ enum m355_dist {
   M355_SKEW_STUDENTT = 41,             /* skew_studentt.py */
   M355_SKEWNORMAL = 42,                /* skewnormal.py (cdf through Owen's T; ppf: find_ppf) */
   M355_VONMISES = 43,                  /* vonmises.py (cdf: helper.py:337-372; ppf: find_ppf) */
-  M355_DIST_COUNT = 44
+  M355_RICE = 44,                      /* rice.py (cdf: ncx2 series / Marcum-Q complement, helper.py:449-539) */
+  M355_DIST_COUNT = 45
 };
 
 /* function ids: the reference function of that module */

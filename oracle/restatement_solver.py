@@ -1,7 +1,7 @@
 """CPU oracle for the solver families -- TEST INFRASTRUCTURE ONLY.
 
 NumPy/SciPy float64 restatement, line by line, of the reference modules wald.py, exgaussian.py,
-truncatednormal.py, skew_studentt.py, skewnormal.py, vonmises.py (+ helper.py:337-372) and of `find_ppf` (optimization.py:10-32); citations are
+truncatednormal.py, skew_studentt.py, skewnormal.py, vonmises.py (+ helper.py:337-372), rice.py (+ helper.py:449-539) and of `find_ppf` (optimization.py:10-32); citations are
 file:line of /root/reference/pytensor_distributions.  Pinned against the reference's own SciPy
 grids (tests/test_wald.py:10-19, test_exgaussian.py:10-18, test_truncatednormal.py:10-26,
 test_skew_studentt.py:11-21) by tests/test_oracle_pinning.py.  Only tests/,
@@ -390,6 +390,82 @@ def vonmises_ppf(q, mu, kappa):  # vonmises.py:73-74 (x0 = mean = mu)
 @_wrap
 def vonmises_isf(q, mu, kappa):  # vonmises.py:69-70
     return vonmises_ppf(1 - q, mu, kappa)
+
+
+# -------------------------------------------------------------------------------------- rice.py
+def ncx2_cdf(x, df, nc):
+    """helper.py:449-512: 800-term Poisson-weighted series of gammainc for nc < 1000, normal approximation above."""
+    x, nc = np.broadcast_arrays(*_f(x, nc))
+    half_nc, half_df, half_x = nc / 2.0, df / 2.0, x / 2.0
+    with _quiet():
+        log_half_nc = sw(half_nc > 0, np.log(half_nc), -inf)
+        series = np.zeros(x.shape)
+        for lo in range(0, 800, 100):  # the reference builds the (800, ...) array at once; summed in order here
+            j = np.arange(lo, lo + 100, dtype=_F).reshape((-1,) + (1,) * x.ndim)
+            log_w = -half_nc + j * log_half_nc - sp.gammaln(j + 1)
+            w = np.exp(np.clip(log_w, -700, 700))
+            series = series + np.sum(w * sp.gammainc(half_df + j, half_x), axis=0)
+        mean_approx = df + nc
+        std_approx = np.sqrt(2 * (df + 2 * nc))
+        normal_result = 0.5 * (1 + sp.erf((x - mean_approx) / (std_approx * np.sqrt(2))))
+    return sw(nc < 1000, series, normal_result)
+
+
+def marcum_q1_complement(a, b):  # helper.py:515-539
+    a, b = _f(a, b)
+    return sw(b <= 0, 0.0, ncx2_cdf(b**2, 2.0, a**2))
+
+
+def _laguerre_half(q):  # rice.py:13-22
+    return (1 + q) * sp.ive(0, q / 2) + q * sp.ive(1, q / 2)
+
+
+def _rice_mean(nu, sigma):  # rice.py:25-28
+    return sigma * np.sqrt(np.pi / 2) * _laguerre_half(nu**2 / (2 * sigma**2))
+
+
+@_wrap
+def rice_logpdf(x, nu, sigma):  # rice.py:65-78
+    sigma2 = sigma**2
+    z = x * nu / sigma2
+    r = np.log(x) - 2 * np.log(sigma) - (x**2 + nu**2) / (2 * sigma2) + np.log(sp.ive(0, z)) + z
+    return sw(x <= 0, -inf, sw(np.isinf(x), np.nan, r))
+
+
+@_wrap
+def rice_pdf(x, nu, sigma):  # rice.py:61-62
+    return np.exp(rice_logpdf(x, nu, sigma))
+
+
+@_wrap
+def rice_cdf(x, nu, sigma):  # rice.py:81-83
+    return cdf_bounds(marcum_q1_complement(nu / sigma, x / sigma), x, 0, inf)
+
+
+@_wrap
+def rice_logcdf(x, nu, sigma):  # rice.py:86-91
+    return sw(x <= 0, -inf, np.log(rice_cdf(x, nu, sigma)))
+
+
+@_wrap
+def rice_sf(x, nu, sigma):  # rice.py:94-95
+    return 1.0 - rice_cdf(x, nu, sigma)
+
+
+@_wrap
+def rice_logsf(x, nu, sigma):  # rice.py:98-99
+    return np.log(rice_sf(x, nu, sigma))
+
+
+@_wrap
+def rice_ppf(q, nu, sigma):  # rice.py:102-103
+    q, nu, sigma = np.broadcast_arrays(q, nu, sigma)
+    return find_ppf(q, _rice_mean(nu, sigma), 0, inf, rice_cdf, rice_pdf, nu, sigma)
+
+
+@_wrap
+def rice_isf(q, nu, sigma):  # rice.py:106-107
+    return rice_ppf(1.0 - q, nu, sigma)
 
 
 SOLVER_TABLE = {k: v for k, v in list(globals().items())

@@ -208,8 +208,9 @@ def test_families_dense_parity(gpu, name, sp_dist, params, sp_params, support, k
     points (+ the support ends and out-of-support points) against the oracle at 1e-12."""
     rng = np.random.default_rng(17)
     d = sp_dist(**sp_params)
-    xs = np.concatenate([np.asarray(d.rvs(20_000, random_state=rng), dtype=np.float64), H.extended_vals(d, support)])
-    qs = np.concatenate([rng.uniform(0, 1, 20_000), H.ISF_POINTS, [1e-12, 1 - 1e-12]])
+    nx, nq = H.SLOW_ORACLE.get(name, (20_000, 20_000))
+    xs = np.concatenate([np.asarray(d.rvs(nx, random_state=rng), dtype=np.float64), H.extended_vals(d, support)])
+    qs = np.concatenate([rng.uniform(0, 1, nq), H.ISF_POINTS, [1e-12, 1 - 1e-12]])
     for fn in ALL_FNS:
         pts = qs if fn in ("ppf", "isf") else xs
         with np.errstate(all="ignore"):

@@ -291,6 +291,7 @@ FAMILY_RVS = [
     ("skew_studentt", (8.0, 4.0, 0.0, 1.0), lambda: stats.jf_skew_t(a=8.0, b=4.0, loc=0.0, scale=1.0)),
     ("skewnormal", (0.5, 1.0, -2.0), lambda: stats.skewnorm(a=-2.0, loc=0.5, scale=1.0)),
     ("vonmises", (0.5, 2.0), lambda: stats.vonmises(kappa=2.0, loc=0.5)),
+    ("rice", (3.0, 2.0), lambda: stats.rice(b=1.5, scale=2.0)),
 ]
 
 
