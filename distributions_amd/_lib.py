@@ -60,6 +60,7 @@ PARAMS = {
     "skewnormal": ('mu', 'sigma', 'alpha'),
     "vonmises": ('mu', 'kappa'),
     "rice": ('nu', 'sigma'),
+    "polyagamma": ('h', 'z'),
 }
 DIST = {name: i for i, name in enumerate(PARAMS)}
 NPARAMS = {name: len(ps) for name, ps in PARAMS.items()}

@@ -46,4 +46,5 @@
   X(M355_SKEW_STUDENTT, skew_studentt, 4) \
   X(M355_SKEWNORMAL, skewnormal, 3) \
   X(M355_VONMISES, vonmises, 2) \
-  X(M355_RICE, rice, 2)
+  X(M355_RICE, rice, 2) \
+  X(M355_POLYAGAMMA, polyagamma, 2)

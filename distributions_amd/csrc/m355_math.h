@@ -21,8 +21,8 @@
 #include <math.h>
 #define M355_DEV inline
 #define M355_HD inline
-#define M355_DEV_HEAVY inline
-#define M355_HD_HEAVY inline
+#define M355_DEV_HEAVY static inline
+#define M355_HD_HEAVY static inline
 #endif
 
 namespace m355 {

@@ -403,6 +403,14 @@ template <int D> M355_DEV double sample_one(unsigned long long idx, unsigned lon
     double u3, u4;
     next_pair(st, u3, u4);
     return (p[0] + p[1] * z0) + (-flog(u3) * p[2]);
+  } else if constexpr (D == M355_POLYAGAMMA) {  // polyagamma.py:191-208: truncated (K = 200) sum-of-gammas representation
+    const double z2 = (p[1] * p[1]) / (4.0 * kPi * kPi);
+    double acc = 0.0;
+    for (int j = 1; j <= 200; ++j) {
+      const double d = ((double)j - 0.5) * ((double)j - 0.5) + z2;
+      acc += sample_std_gamma(st, p[0]) / d;
+    }
+    return acc / (2.0 * kPi * kPi);
   } else if constexpr (D == M355_RICE) {  // rice.py:110-113: |(nu + sigma z0, sigma z1)|
     double u1, u2, z0, z1;
     next_pair(st, u1, u2);

@@ -91,7 +91,8 @@ enum m355_dist {
   M355_SKEWNORMAL = 42,                /* skewnormal.py (cdf through Owen's T; ppf: find_ppf) */
   M355_VONMISES = 43,                  /* vonmises.py (cdf: helper.py:337-372; ppf: find_ppf) */
   M355_RICE = 44,                      /* rice.py (cdf: ncx2 series / Marcum-Q complement, helper.py:449-539) */
-  M355_DIST_COUNT = 45
+  M355_POLYAGAMMA = 45,                /* polyagamma.py (series density :31-68, trapezoid cdf :124-134, Newton ppf :149-184) */
+  M355_DIST_COUNT = 46
 };
 
 /* function ids: the reference function of that module */

@@ -1,7 +1,7 @@
 """CPU oracle for the solver families -- TEST INFRASTRUCTURE ONLY.
 
 NumPy/SciPy float64 restatement, line by line, of the reference modules wald.py, exgaussian.py,
-truncatednormal.py, skew_studentt.py, skewnormal.py, vonmises.py (+ helper.py:337-372), rice.py (+ helper.py:449-539) and of `find_ppf` (optimization.py:10-32); citations are
+truncatednormal.py, skew_studentt.py, skewnormal.py, vonmises.py (+ helper.py:337-372), rice.py (+ helper.py:449-539), polyagamma.py and of `find_ppf` (optimization.py:10-32); citations are
 file:line of /root/reference/pytensor_distributions.  Pinned against the reference's own SciPy
 grids (tests/test_wald.py:10-19, test_exgaussian.py:10-18, test_truncatednormal.py:10-26,
 test_skew_studentt.py:11-21) by tests/test_oracle_pinning.py.  Only tests/,
@@ -466,6 +466,103 @@ def rice_ppf(q, nu, sigma):  # rice.py:102-103
 @_wrap
 def rice_isf(q, nu, sigma):  # rice.py:106-107
     return rice_ppf(1.0 - q, nu, sigma)
+
+
+# -------------------------------------------------------------------------------- polyagamma.py
+_PG_LOWER = 1e-10  # polyagamma.py:15-16
+
+
+def _pg_log_cosh_half(z):  # polyagamma.py:25-28
+    a = np.abs(z / 2)
+    return a + np.log1p(np.exp(-2 * a)) - np.log(2.0)
+
+
+def _pg_log_density_base(x, h, N=20):  # polyagamma.py:31-68
+    n = np.arange(N, dtype=_F).reshape((-1,) + (1,) * np.ndim(x))
+    c = 2 * n + h
+    signs = sw(n % 2 == 0, 1.0, -1.0)
+    log_abs = (sp.gammaln(n + h) - sp.gammaln(n + 1) + np.log(c) - 0.5 * np.log(2 * np.pi) - 1.5 * np.log(x)
+               - c**2 / (8 * x))
+    max_log = np.max(log_abs, axis=0)
+    signed_sum = np.sum(signs * np.exp(log_abs - max_log), axis=0)
+    log_series = np.log(np.maximum(signed_sum, 1e-300)) + max_log
+    return (h - 1) * np.log(2.0) - sp.gammaln(h) + log_series
+
+
+def _pg_mean(h, z):  # polyagamma.py:71-77
+    small = np.abs(z) < 1e-6
+    sz = sw(small, 1.0, z)
+    return sw(small, h / 4.0, h / (2 * sz) * np.tanh(sz / 2))
+
+
+def _pg_var(h, z):  # polyagamma.py:88-94
+    small = np.abs(z) < 1e-6
+    sz = sw(small, 1.0, z)
+    return sw(small, h / 24.0, h / (4 * sz**3) * (np.sinh(sz) - sz) / np.cosh(sz / 2) ** 2)
+
+
+@_wrap
+def polyagamma_logpdf(x, h, z):  # polyagamma.py:113-117
+    x, h, z = np.broadcast_arrays(x, h, z)
+    r = h * _pg_log_cosh_half(z) - z**2 * x / 2 + _pg_log_density_base(x, h)
+    return sw(x <= 0, -inf, r)
+
+
+@_wrap
+def polyagamma_pdf(x, h, z):  # polyagamma.py:120-121
+    return np.exp(polyagamma_logpdf(x, h, z))
+
+
+@_wrap
+def polyagamma_cdf(x, h, z):  # polyagamma.py:124-134: 500-point trapezoid of the pdf from 1e-10 to x
+    x, h, z = np.broadcast_arrays(x, h, z)
+    n_points = 500
+    step = (x - _PG_LOWER) / (n_points - 1)
+    i = np.arange(n_points, dtype=_F).reshape((-1,) + (1,) * x.ndim)
+    t = _PG_LOWER + i * step  # pt.linspace
+    pv = polyagamma_pdf(t, h, z)
+    result = step * (0.5 * pv[0] + np.sum(pv[1:-1], axis=0) + 0.5 * pv[-1])
+    return cdf_bounds(result, x, 0, inf)
+
+
+@_wrap
+def polyagamma_logcdf(x, h, z):  # polyagamma.py:137-138
+    return sw(x <= 0, -inf, np.log(polyagamma_cdf(x, h, z)))
+
+
+@_wrap
+def polyagamma_sf(x, h, z):  # polyagamma.py:141-142
+    return 1.0 - polyagamma_cdf(x, h, z)
+
+
+@_wrap
+def polyagamma_logsf(x, h, z):  # polyagamma.py:145-146
+    return np.log1p(-polyagamma_cdf(x, h, z))
+
+
+@_wrap
+def polyagamma_ppf(q, h, z, max_iter=50, tol=1e-8):  # polyagamma.py:149-184
+    q, h, z = np.broadcast_arrays(q, h, z)
+    m, v = _pg_mean(h, z), _pg_var(h, z)
+    s2 = np.log1p(v / m**2)
+    mu_ln = np.log(m) - s2 / 2
+    x = np.exp(mu_ln + np.sqrt(s2) * np.sqrt(2.0) * sp.erfinv(2 * q - 1))
+    x = np.maximum(x, _PG_LOWER)
+    for _ in range(max_iter):
+        delta = (polyagamma_cdf(x, h, z) - q) / np.maximum(polyagamma_pdf(x, h, z), 1e-10)
+        ms = np.maximum(np.abs(x), 0.5)
+        delta = sw(delta < -ms, -ms, sw(delta > ms, ms, delta))
+        x_new = np.maximum(x - delta, _PG_LOWER)
+        converged = np.abs(x_new - x) < tol
+        x = sw(converged, x, x_new)
+        if np.all(converged):
+            break
+    return ppf_bounds_cont(x, q, 0, inf)
+
+
+@_wrap
+def polyagamma_isf(q, h, z):  # polyagamma.py:187-188
+    return polyagamma_ppf(1.0 - q, h, z)
 
 
 SOLVER_TABLE = {k: v for k, v in list(globals().items())

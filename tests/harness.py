@@ -365,3 +365,17 @@ def grad_close(got, exp, info, tol=1e-12):
 
 # families whose oracle is too slow for 20k-point sweeps (rice: 800-term series per cdf, 100 Newton steps per quantile)
 SLOW_ORACLE = {"rice": (1500, 48), "vonmises": (20_000, 1500)}  # (points for x-functions, points for ppf / isf)
+
+# polyagamma has no SciPy counterpart: parameter sets of the reference's empirical test (tests/test_polyagamma.py:13-17)
+POLYAGAMMA_CASES = [(1.0, 0.0), (2.0, 2.0), (0.5, 1.0)]
+
+
+def polyagamma_points(rng, h, z, nx=600, nq=24):
+    """Evaluation points for polyagamma: draws of the reference's own sum-of-gammas representation
+    (polyagamma.py:191-208), the support end, out-of-support points and a few probabilities."""
+    k = np.arange(1, 201, dtype=np.float64)[:, None]
+    g = rng.gamma(h, 1.0, size=(200, nx))
+    draws = (g / ((k - 0.5) ** 2 + z * z / (4 * np.pi**2))).sum(axis=0) / (2 * np.pi**2)
+    xs = np.concatenate([draws, [0.0, -1.0, -2.0, np.inf, 1e-12, 1e-3, 50.0]])
+    qs = np.concatenate([rng.uniform(0.01, 0.99, nq), ISF_POINTS])
+    return xs, qs

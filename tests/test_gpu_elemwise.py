@@ -280,3 +280,33 @@ def test_discrete_families_dense_parity(gpu, name, params, support):
     if fin.any():
         tot = m.sum_logpdf(k[fin], *params)
         assert abs(tot - math.fsum(exp[fin])) <= 1e-12 * float(np.abs(exp[fin]).sum())
+
+
+@pytest.mark.parametrize("h, z", H.POLYAGAMMA_CASES)
+def test_polyagamma(gpu, h, z):
+    """polyagamma: no SciPy counterpart -- every function against the oracle (series density,
+    500-point trapezoid cdf, the module's own Newton ppf), plus cdf(ppf(q)) = q and the bounds of the reference's
+    test (tests/test_polyagamma.py:60-66)."""
+    from distributions_amd import polyagamma
+
+    xs, qs = H.polyagamma_points(np.random.default_rng(42), h, z)
+    for fn in ALL_FNS:
+        pts = qs if fn in ("ppf", "isf") else xs
+        with np.errstate(all="ignore"):
+            exp = R.TABLE[f"polyagamma_{fn}"](pts, h, z)
+        got = getattr(polyagamma, fn)(pts, h, z)
+        tol = 1e-9 if fn in ("ppf", "isf") else 1e-12  # Newton on a cdf that carries ~1e-14 of summation noise
+        ok = H.close(got, exp, tol) | H.cancellation_ok(fn, got, exp)
+        assert np.all(ok), (fn, h, z, pts[~ok][:4], got[~ok][:4], exp[~ok][:4])
+    q = np.linspace(0.05, 0.95, 10)
+    assert np.allclose(polyagamma.cdf(polyagamma.ppf(q, h, z), h, z), q, rtol=0, atol=1e-7)
+    ext = np.array([0.0, np.inf, -1.0, -2.0, np.inf, np.inf])
+    assert np.array_equal(polyagamma.cdf(ext, h, z), [0.0, 1.0, 0.0, 0.0, 1.0, 1.0])
+    # rvs: KS against the module's own cdf, mean against the closed form (tests/test_polyagamma.py:34-41)
+    from scipy import stats
+
+    x = polyagamma.rvs(h, z, size=50_000, random_state=8)
+    assert x.dtype == np.float64 and np.all(x > 0)
+    assert stats.kstest(x[:4000], lambda v: R.TABLE["polyagamma_cdf"](v, h, z)).pvalue > 1e-3
+    mean = h / 4.0 if z == 0 else h / (2 * z) * np.tanh(z / 2)
+    assert abs(x.mean() - mean) <= 3e-2 * mean

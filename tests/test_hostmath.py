@@ -302,3 +302,18 @@ def test_host_grad_vs_oracle(hostlib, name, sp_dist, params, sp_params, support,
     got = host_grad(hostlib, name, xs, params)
     val, grads = G.logpdf_grad(name, xs, *params)
     assert H.grad_close(got.T, [val] + grads, (name, params, xs))
+
+
+@pytest.mark.parametrize("h, z", H.POLYAGAMMA_CASES)
+def test_host_polyagamma_vs_oracle(hostlib, h, z):
+    """Series density and trapezoid cdf of polyagamma (csrc/m355_dists4.h) against the oracle at 1e-12; ppf / isf
+    start from erfinv (device libm only) and are GPU-tested."""
+    xs, _ = H.polyagamma_points(np.random.default_rng(41), h, z, nx=300)
+    fns = ["logpdf", "pdf", "cdf", "logcdf", "sf", "logsf"]
+    ns = host_namespace(hostlib, "polyagamma", fns)
+    for fn in fns:
+        with np.errstate(all="ignore"):
+            exp = R.TABLE[f"polyagamma_{fn}"](xs, h, z)
+        got = getattr(ns, fn)(xs, h, z)
+        ok = _close(got, exp) | H.cancellation_ok(fn, got, exp)
+        assert np.all(ok), (fn, h, z, xs[~ok][:5], got[~ok][:5], exp[~ok][:5])

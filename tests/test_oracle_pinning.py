@@ -169,6 +169,30 @@ def test_oracle_discrete_without_scipy(name, params):
     assert np.all(np.isnan(edge))
 
 
+@pytest.mark.parametrize("h, z", [(1.0, 0.0), (2.0, 2.0), (0.5, 1.0)])  # tests/test_polyagamma.py:13-17
+def test_oracle_polyagamma(h, z):
+    """polyagamma has no SciPy counterpart (the reference tests it against its own samples at rtol 3e-2 .. 3e-1,
+    tests/test_polyagamma.py:34-57): the restated density is pinned on what defines PG(h, z) -- total mass 1, the
+    mean h/(2z) tanh(z/2), and the Laplace transform E exp(-t X) = (cosh(z/2) / cosh(sqrt((z^2/2 + t)/2)))^h -- and
+    the restated cdf (a 500-point trapezoid, polyagamma.py:124-134) on the integral of that density."""
+    from scipy.integrate import quad
+
+    pdf = lambda x: float(R.TABLE["polyagamma_pdf"](x, h, z))  # noqa: E731
+    assert abs(quad(pdf, 0, np.inf, limit=200)[0] - 1.0) < 1e-10
+    mean = h / 4.0 if z == 0 else h / (2 * z) * np.tanh(z / 2)
+    assert abs(quad(lambda x: x * pdf(x), 0, np.inf, limit=200)[0] - mean) < 1e-10
+    for t in (0.3, 1.3, 7.0):
+        exact = (np.cosh(z / 2) / np.cosh(np.sqrt((z * z / 2 + t) / 2))) ** h
+        assert abs(quad(lambda x: np.exp(-t * x) * pdf(x), 0, np.inf, limit=200)[0] - exact) < 1e-10
+    xs = np.array([0.05, 0.2, 0.5, 1.0])
+    assert_allclose(R.TABLE["polyagamma_cdf"](xs, h, z), [quad(pdf, 0, x)[0] for x in xs], rtol=1e-4)
+    ext = np.array([0.0, np.inf, -1.0, -2.0])  # tests/test_polyagamma.py:60-66
+    assert_allclose(R.TABLE["polyagamma_cdf"](ext, h, z), [0.0, 1.0, 0.0, 0.0])
+    q = np.array([0.05, 0.35, 0.65, 0.95])
+    assert_allclose(R.TABLE["polyagamma_cdf"](R.TABLE["polyagamma_ppf"](q, h, z), h, z), q, atol=1e-7)
+    assert_allclose(R.TABLE["polyagamma_isf"](q, h, z), R.TABLE["polyagamma_ppf"](1 - q, h, z))
+
+
 def test_oracle_edge_table_survey_appendix_c():
     """Edge values recorded in SURVEY.md Appendix C (literal float64 restatement)."""
     inf = np.inf

@@ -23,7 +23,7 @@ def test_optional_dependency_boundary():
             importlib.import_module("distributions_amd.pytensor_ops")
     from distributions_amd.csrc_support import SUPPORTED
 
-    assert ("normal", "ppf") in SUPPORTED and ("poisson", "ppf") in SUPPORTED and len(SUPPORTED) == 8 * 45
+    assert ("normal", "ppf") in SUPPORTED and ("poisson", "ppf") in SUPPORTED and len(SUPPORTED) == 8 * 46
 
 
 @pytest.mark.gpu
