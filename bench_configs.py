@@ -172,6 +172,34 @@ def config7(torch, n):
         del x
 
 
+def config8(torch, n):
+    """Solver / series families: logpdf, cdf and ppf, scalar parameters, points drawn from each
+    distribution's own rvs kernel.  These are instruction-bound (series, quadrature, Newton iterations per element):
+    the figure of merit is evaluations/s; sizes are reduced where one evaluation costs 1e4 .. 1e6 operations."""
+    from distributions_amd import _dispatch, raw
+
+    cases = {"wald": ((2.0, 10.0), 1.0, 1.0), "exgaussian": ((1.0, 3.0, 3.0), 1.0, 1.0),
+             "truncatednormal": ((2.0, 1.5, -1.0, 5.0), 1.0, 1.0), "skew_studentt": ((8.0, 4.0, 0.0, 1.0), 1.0, 1.0),
+             "skewnormal": ((0.5, 1.0, -2.0), 1.0, 1.0), "vonmises": ((0.5, 2.0), 1.0, 0.1),
+             "rice": ((3.0, 2.0), 0.1, 0.01), "polyagamma": ((1.0, 0.0), 0.1, 0.01)}
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev).manual_seed(9)
+    for name, (p, f_cdf, f_ppf) in cases.items():
+        x = _dispatch.rvs(name, p, size=n, random_state=3, as_torch=True)
+        q = torch.rand(n, dtype=torch.float64, device=dev, generator=g).clamp_(1e-6, 1 - 1e-6)
+        out = torch.empty(n, dtype=torch.float64, device=dev)
+        row = {"config": 8, "dist": name}
+        for fn, frac in (("logpdf", 1.0), ("cdf", f_cdf), ("ppf", f_ppf)):
+            m = max(1024, int(n * frac))
+            src = (q if fn == "ppf" else x)[:m]
+            ms = timed(torch, lambda: raw.elemwise_into(name, fn, src, p, out[:m]), reps=3, warmup=1)
+            row[f"{fn}_n"] = m
+            row[f"{fn}_ms"] = round(ms, 4)
+            row[f"{fn}_evals_per_s"] = float(f"{m / (ms * 1e-3):.4g}")
+        print(json.dumps(row), flush=True)
+        del x, q, out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--config", default="all")
@@ -190,6 +218,8 @@ def main():
         config6(torch, args.n or 100_000_000)
     if args.config in ("7", "all"):
         config7(torch, args.n or 100_000_000)
+    if args.config in ("8", "all"):
+        config8(torch, args.n or 10_000_000)
 
 
 if __name__ == "__main__":
