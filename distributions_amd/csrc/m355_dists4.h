@@ -1,6 +1,7 @@
-// Scalar bodies of the solver families: wald, exgaussian (ppf by the reference's
-// clipped Newton iteration find_ppf, optimization.py:10-32, run per lane with early exit), truncatednormal
-// and skew_studentt (closed-form ppf).  Same Dist<D>::derive / eval<FN> template as m355_dists.h; every
+// Scalar bodies of the solver and series families: wald, exgaussian, skewnormal (Owen's T),
+// vonmises (Bessel-ratio series), rice (scaled Bessel functions, ncx2 / Marcum-Q sum) -- ppf by the reference's
+// clipped Newton iteration find_ppf, optimization.py:10-32, run per lane with early exit -- polyagamma (series
+// density, trapezoid cdf, its own Newton ppf), and truncatednormal, skew_studentt (closed-form ppf).  Same Dist<D>::derive / eval<FN> template as m355_dists.h; every
 // formula follows the reference line by line (file:line cited; paths relative to
 // /root/reference/pytensor_distributions), its cancellations included (wald.cdf's e^{2 lam/mu} (1 + erf(-t))).
 #pragma once
