@@ -78,6 +78,7 @@ template <> struct Dist<M355_NORMAL> {
 // ---------------------------------------------------------------------------------------- gamma
 template <> struct Dist<M355_GAMMA> {
   static constexpr int NP = 2;
+  static constexpr bool kLogTable = true;  // logpdf uses flog_tab
   struct K {
     double alpha, beta, am1, c, lga;
   };
@@ -92,7 +93,7 @@ template <> struct Dist<M355_GAMMA> {
   }
   // gamma.py:77-82 with (alpha-1)*log(x) as xlogy0 (quirk Q2).
   static M355_DEV double logpdf(double x, const K& k) {
-    const double t = xlogy0_l(k.am1, flog_stream(x));
+    const double t = xlogy0_l(k.am1, flog_tab(x));
     const double r = (t - x * k.beta) + k.c;
     return (x < 0.0) ? -kInf : r;
   }
@@ -138,6 +139,7 @@ template <> struct Dist<M355_GAMMA> {
 // ----------------------------------------------------------------------------------------- beta
 template <> struct Dist<M355_BETA> {
   static constexpr int NP = 2;
+  static constexpr bool kLogTable = true;  // logpdf uses flog_tab
   struct K {
     double a, b, am1, bm1, lbeta;
   };
@@ -153,7 +155,7 @@ template <> struct Dist<M355_BETA> {
   }
   // beta.py:102-108; xlogy0(alpha+beta-1, 1) is a*log(1) == 0 (or the xlogy0 zero).
   static M355_DEV double logpdf(double x, const K& k) {
-    const double t = xlogy0_l(k.am1, flog_stream(x)) + xlogy0_l(k.bm1, flog_stream(1.0 - x));
+    const double t = xlogy0_l(k.am1, flog_tab(x)) + xlogy0_l(k.bm1, flog_tab(1.0 - x));
     const double r = t - (0.0 + k.lbeta);
     return ((x < 0.0) | (x > 1.0)) ? -kInf : r;
   }
@@ -187,6 +189,7 @@ template <> struct Dist<M355_BETA> {
 // ------------------------------------------------------------------------------------- studentt
 template <> struct Dist<M355_STUDENTT> {
   static constexpr int NP = 3;
+  static constexpr bool kLogTable = true;  // logpdf uses flog1p_tab
   struct K {
     double nu, mu, sigma, c, hnp1, inv_s2nu, lbeta_h;  // lbeta_h = betaln(nu/2, 1/2)
   };
@@ -208,7 +211,7 @@ template <> struct Dist<M355_STUDENTT> {
   static M355_DEV double logpdf(double x, const K& k) {
     if (k.nu > 1e5) return normal_logcdf_z((x - k.mu) / k.sigma);
     const double d = x - k.mu;
-    return k.c - k.hnp1 * flog1p_stream(d * d * k.inv_s2nu);
+    return k.c - k.hnp1 * flog1p_tab(d * d * k.inv_s2nu);
   }
   // studentt.py:100-105.  The nu > 1e5 arm is normal.CDF(z, mu, sigma) on the already
   // standardised z (mis-import studentt.py:6); reproduced as is (quirk Q1).

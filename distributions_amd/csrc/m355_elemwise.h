@@ -116,12 +116,17 @@ M355_DEV double block_reduce_sum(double v) {
   return v;
 }
 
+// Dist<D>::kLogTable: the bodies use flog_tab (m355_math.h), whose LDS table every kernel fills first.
+template <class T, class = void> struct uses_log_table : std::false_type {};
+template <class T> struct uses_log_table<T, std::void_t<decltype(T::kLogTable)>> : std::true_type {};
+
 template <int D, int FN, bool REDUCE, bool F64IO>
 __global__ __launch_bounds__(kBlock) void k_scalar(const void* __restrict__ x, int xdt,
                                                    void* __restrict__ out, int odt, long long n,
                                                    const typename Dist<D>::K k,
                                                    double* __restrict__ partials) {
   using DD = Dist<D>;
+  if constexpr (uses_log_table<DD>::value) log_table_init();
   const long long ntiles = n / kTile;
   double acc = 0.0;
   for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -166,6 +171,7 @@ __global__ __launch_bounds__(kBlock) void k_periodic(const void* __restrict__ x,
   using K = typename DD::K;
   constexpr int NK = sizeof(K) / sizeof(double);
   extern __shared__ double lds[];  // [NK][P]
+  if constexpr (uses_log_table<DD>::value) log_table_init();
   for (unsigned j = threadIdx.x; j < P; j += kBlock) {
     double pp[kMaxParams];
 #pragma unroll
@@ -248,6 +254,7 @@ template <int D, int FN, bool REDUCE>
 __global__ __launch_bounds__(kBlock) void k_generic(GenericOps ops, void* __restrict__ out, int odt,
                                                     long long n, double* __restrict__ partials) {
   using DD = Dist<D>;
+  if constexpr (uses_log_table<DD>::value) log_table_init();
   const bool small = n <= 0xffffffffll;
   double acc = 0.0;
   for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < n; i += (long long)gridDim.x * kBlock) {

@@ -60,6 +60,7 @@ extern "C" void hm_betaincinv(long n, const double* a, const double* b, const do
 }
 extern "C" void hm_lbeta(long n, const double* a, const double* b, double* out) { for (long i = 0; i < n; ++i) out[i] = lbeta_(a[i], b[i]); }
 extern "C" void hm_log_stream(long n, const double* x, double* out) { for (long i = 0; i < n; ++i) out[i] = flog_stream(x[i]); }
+extern "C" void hm_log_tab(long n, const double* x, double* out) { for (long i = 0; i < n; ++i) out[i] = flog_tab(x[i]); }
 extern "C" void hm_log1p_stream(long n, const double* x, double* out) { for (long i = 0; i < n; ++i) out[i] = flog1p_stream(x[i]); }
 
 #include "../../distributions_amd/csrc/m355_rng.h"
