@@ -196,6 +196,7 @@ __global__ __launch_bounds__(kBlock) void k_multinomial_rvs(const double* __rest
                                                             long long* __restrict__ out, long long rows,
                                                             unsigned long long seed, unsigned stream,
                                                             unsigned long long offset) {
+  log_table_init();  // sample_binomial uses flog_tab
   for (long long r = (long long)blockIdx.x * kBlock + threadIdx.x; r < rows; r += (long long)gridDim.x * kBlock) {
     const unsigned long long c = offset + (unsigned long long)r;
     RngState st;

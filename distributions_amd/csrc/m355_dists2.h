@@ -664,6 +664,7 @@ template <> struct Dist<M355_HALFSTUDENTT> {
 // ----------------------------------------------------------------------------------- betascaled
 template <> struct Dist<M355_BETASCALED> {
   static constexpr int NP = 4;
+  static constexpr bool kLogTable = true;  // logpdf uses flog_tab
   struct K { double a, b, lo, hi, w, lbeta, c; };  // c = xlogy0(a+b-1, hi-lo) + betaln(a, b)
   static M355_HD K derive(const double* p) {
     K k;
@@ -678,7 +679,7 @@ template <> struct Dist<M355_BETASCALED> {
   }
   static M355_DEV double logpdf(double x, const K& k) {  // betascaled.py:106-112
     if ((x < k.lo) | (x > k.hi)) return -kInf;
-    return (xlogy0_l(k.a - 1.0, flog(x - k.lo)) + xlogy0_l(k.b - 1.0, flog(k.hi - x))) - k.c;
+    return (xlogy0_l(k.a - 1.0, flog_tab(x - k.lo)) + xlogy0_l(k.b - 1.0, flog_tab(k.hi - x))) - k.c;
   }
   static M355_DEV double logcdf(double x, const K& k) {  // betascaled.py:97-103
     if (x < k.lo) return -kInf;

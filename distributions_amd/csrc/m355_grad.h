@@ -116,8 +116,8 @@ template <unsigned A> M355_HD auto operator/(double b, const Dual<A>& a) {
 M355_HD double dlog(double a) { return flog(a); }
 M355_HD double dlog1p(double a) { return flog1p(a); }
 M355_HD double dsqr(double a) { return a * a; }
-template <unsigned A> M355_HD auto dlog(const Dual<A>& a) { return chain(flog_stream(a.v), 1.0 / a.v, a); }
-template <unsigned A> M355_HD auto dlog1p(const Dual<A>& a) { return chain(flog1p_stream(a.v), 1.0 / (1.0 + a.v), a); }
+template <unsigned A> M355_HD auto dlog(const Dual<A>& a) { return chain(flog_tab(a.v), 1.0 / a.v, a); }
+template <unsigned A> M355_HD auto dlog1p(const Dual<A>& a) { return chain(flog1p_tab(a.v), 1.0 / (1.0 + a.v), a); }
 template <unsigned A> M355_DEV auto dexp(const Dual<A>& a) {
   const double e = exp_(a.v);
   return chain(e, e, a);
@@ -135,7 +135,7 @@ template <unsigned A, unsigned B> M355_DEV auto dpow(const Dual<A>& a, const Dua
 }
 // pytensor.tensor.xlogx.XlogY0: value 0 where a == 0; grad [gz * log(y), gz * a / y]
 template <unsigned A, unsigned B> M355_HD auto dxlogy0(const Dual<A>& a, const Dual<B>& y) {
-  const double ly = flog_stream(y.v);
+  const double ly = flog_tab(y.v);
   return comb(a.v == 0.0 ? 0.0 : a.v * ly, ly, a, a.v / y.v, y);
 }
 // pt.switch as a select: value and partials of the selected arm (real selects: the dead arm's NaNs stay dead)

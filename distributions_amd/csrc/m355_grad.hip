@@ -50,6 +50,7 @@ __global__ __launch_bounds__(kBlock) void k_grad_scalar(const void* __restrict__
                                                         double* __restrict__ partials) {
   using G = Grad<D>;
   constexpr int S = 2 + G::NP;
+  log_table_init();  // dlog / dlog1p / dxlogy0 use flog_tab
   const auto k = grad_pre<G>(pv.p);
   double acc[S];
 #pragma unroll
@@ -87,6 +88,7 @@ __global__ __launch_bounds__(kBlock) void k_grad_generic(GenericOps ops, GradOut
                                                          double* __restrict__ partials) {
   using G = Grad<D>;
   constexpr int S = 2 + G::NP;
+  log_table_init();  // dlog / dlog1p / dxlogy0 use flog_tab
   const bool small = n <= 0xffffffffll;
   double acc[S];
 #pragma unroll

@@ -89,7 +89,7 @@ M355_DEV void sincos_2pi(double u, double& s, double& c) {
 
 // Two independent standard normals from one uniform pair (Box-Muller).
 M355_DEV void normal_pair(double u1, double u2, double& z0, double& z1) {
-  const double r = fsqrt(-2.0 * flog_stream(u1));
+  const double r = fsqrt(-2.0 * flog_tab(u1));
   double s, c;
   sincos_2pi(u2, s, c);
   z0 = r * c;
@@ -124,7 +124,7 @@ M355_DEV double sample_std_gamma(RngState& st, double a) {
       if (ok || !(t > 0.0)) continue;
       const double vv = t * t * t;
       const double x2 = x * x;
-      if (u < 1.0 - 0.0331 * x2 * x2 || flog_stream(u) < 0.5 * x2 + d * (1.0 - vv + flog_stream(vv))) {
+      if (u < 1.0 - 0.0331 * x2 * x2 || flog_tab(u) < 0.5 * x2 + d * (1.0 - vv + flog_tab(vv))) {
         v = vv;
         ok = true;
       }
@@ -135,7 +135,7 @@ M355_DEV double sample_std_gamma(RngState& st, double a) {
   if (boost) {
     double u1, u2;
     next_pair(st, u1, u2);
-    g *= exp_(flog_stream(u1) / a);
+    g *= exp_(flog_tab(u1) / a);
   }
   return g;
 }
@@ -162,7 +162,7 @@ M355_DEV double lfactorial(double k) {
     return t[(int)k];
   }
   const double z = k + 1.0;
-  return (z - 0.5) * flog_stream(z) - z + kLogSqrt2Pi + stirling_corr(z);
+  return (z - 0.5) * flog_tab(z) - z + kLogSqrt2Pi + stirling_corr(z);
 }
 
 // PTRS (Hoermann 1993, "The transformed rejection method for generating Poisson random
@@ -176,10 +176,10 @@ M355_DEV PtrsK ptrs_setup(double mu) {
   PtrsK c;
   const double slam = fsqrt(mu);
   c.mu = mu;
-  c.loglam = flog_stream(mu);
+  c.loglam = flog_tab(mu);
   c.b = 0.931 + 2.53 * slam;
   c.a = -0.059 + 0.02483 * c.b;
-  c.log_invalpha = flog_stream(1.1239 + 1.1328 / (c.b - 3.4));
+  c.log_invalpha = flog_tab(1.1239 + 1.1328 / (c.b - 3.4));
   c.vr = 0.9277 - 3.6224 / (c.b - 2.0);
   return c;
 }
@@ -190,7 +190,7 @@ M355_DEV bool ptrs_attempt(const PtrsK& c, double u1, double v, double& k) {
   k = floor_((2.0 * c.a / us + c.b) * u + c.mu + 0.43);
   if (us >= 0.07 && v <= c.vr) return true;
   if (k < 0.0 || (us < 0.013 && v > us)) return false;
-  return flog_stream(v) + c.log_invalpha - flog_stream(c.a / (us * us) + c.b) <= -c.mu + k * c.loglam - lfactorial(k);
+  return flog_tab(v) + c.log_invalpha - flog_tab(c.a / (us * us) + c.b) <= -c.mu + k * c.loglam - lfactorial(k);
 }
 
 // Poisson(mu) as a double holding an integer.  mu == 0 -> 0; mu < 0 or NaN -> NaN.
@@ -252,7 +252,7 @@ M355_DEV BtrsK btrs_setup(double n, double p) {
   k.alpha = (2.83 + 5.1 / k.b) * spq;
   k.m = floor_((n + 1.0) * pp);
   // the k-independent part of the acceptance bound
-  k.hm = (k.m + 0.5) * flog_stream((k.m + 1.0) / (k.r * (n - k.m + 1.0))) + stirling_tail(k.m) + stirling_tail(n - k.m);
+  k.hm = (k.m + 0.5) * flog_tab((k.m + 1.0) / (k.r * (n - k.m + 1.0))) + stirling_tail(k.m) + stirling_tail(n - k.m);
   return k;
 }
 M355_DEV bool btrs_attempt(const BtrsK& c, double u1, double v, double& k) {
@@ -261,9 +261,9 @@ M355_DEV bool btrs_attempt(const BtrsK& c, double u1, double v, double& k) {
   k = floor_((2.0 * c.a / us + c.b) * u + c.c);
   if (us >= 0.07 && v <= c.vr) return true;
   if (k < 0.0 || k > c.n) return false;
-  const double lv = flog_stream(v * c.alpha / (c.a / (us * us) + c.b));
-  const double upper = c.hm + (c.n + 1.0) * flog_stream((c.n - c.m + 1.0) / (c.n - k + 1.0)) +
-                       (k + 0.5) * flog_stream(c.r * (c.n - k + 1.0) / (k + 1.0)) - stirling_tail(k) - stirling_tail(c.n - k);
+  const double lv = flog_tab(v * c.alpha / (c.a / (us * us) + c.b));
+  const double upper = c.hm + (c.n + 1.0) * flog_tab((c.n - c.m + 1.0) / (c.n - k + 1.0)) +
+                       (k + 0.5) * flog_tab(c.r * (c.n - k + 1.0) / (k + 1.0)) - stirling_tail(k) - stirling_tail(c.n - k);
   return lv <= upper;
 }
 

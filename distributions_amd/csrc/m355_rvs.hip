@@ -18,6 +18,7 @@ template <int D>
 __global__ __launch_bounds__(kBlock) void k_rvs(GenericOps ops, void* __restrict__ out, int odt, long long n,
                                                 unsigned long long seed, unsigned stream,
                                                 unsigned long long offset) {
+  log_table_init();  // the samplers use flog_tab
   const bool small = n <= 0xffffffffll;
   for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < n; i += (long long)gridDim.x * kBlock) {
     double pp[kMaxParams] = {0.0, 0.0, 0.0, 0.0};
@@ -32,6 +33,7 @@ __global__ __launch_bounds__(kBlock) void k_rvs(GenericOps ops, void* __restrict
 __global__ __launch_bounds__(kBlock) void k_rvs_normal_pairs(double* __restrict__ out, long long npairs, double mu,
                                                              double sigma, unsigned long long seed, unsigned stream,
                                                              unsigned long long pair_offset) {
+  log_table_init();
   for (long long k = (long long)blockIdx.x * kBlock + threadIdx.x; k < npairs; k += (long long)gridDim.x * kBlock) {
     const unsigned long long c = pair_offset + (unsigned long long)k;
     const Philox p = philox4x32_10((unsigned)c, (unsigned)(c >> 32), 0u, stream, (unsigned)seed, (unsigned)(seed >> 32));
@@ -55,6 +57,7 @@ template <int D>
 __global__ __launch_bounds__(kBlock) void k_rvs_compact(void* __restrict__ out, int odt, long long n, double p0, double p1,
                                                         unsigned long long seed, unsigned stream,
                                                         unsigned long long offset) {
+  log_table_init();
   const long long wave = (long long)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
   const long long nwaves = (long long)gridDim.x * (kBlock / 64);
   const long long chunk = ((n + nwaves - 1) / nwaves + 63) & ~63ll;
