@@ -77,6 +77,7 @@ template <> struct Dist<M355_NORMAL> {
 
 // ---------------------------------------------------------------------------------------- gamma
 template <> struct Dist<M355_GAMMA> {
+  static constexpr int kBinned = 1;  // logcdf / logsf / ppf ...: lanes diverge, see k_binned (m355_elemwise.h)
   static constexpr int NP = 2;
   static constexpr bool kLogTable = true;  // logpdf uses flog_tab
   struct K {
@@ -138,6 +139,7 @@ template <> struct Dist<M355_GAMMA> {
 
 // ----------------------------------------------------------------------------------------- beta
 template <> struct Dist<M355_BETA> {
+  static constexpr int kBinned = 1;  // logcdf / logsf / ppf ...: lanes diverge, see k_binned (m355_elemwise.h)
   static constexpr int NP = 2;
   static constexpr bool kLogTable = true;  // logpdf uses flog_tab
   struct K {
@@ -188,6 +190,7 @@ template <> struct Dist<M355_BETA> {
 
 // ------------------------------------------------------------------------------------- studentt
 template <> struct Dist<M355_STUDENTT> {
+  static constexpr int kBinned = 1;  // logcdf / logsf / ppf ...: lanes diverge, see k_binned (m355_elemwise.h)
   static constexpr int NP = 3;
   static constexpr bool kLogTable = true;  // logpdf uses flog1p_tab
   struct K {
@@ -281,6 +284,7 @@ M355_DEV double find_ppf_discrete(double q, double x0, double lower, double uppe
 
 // -------------------------------------------------------------------------------------- poisson
 template <> struct Dist<M355_POISSON> {
+  static constexpr int kBinned = 1;
   static constexpr int NP = 1;
   struct K {
     double mu, logmu;
@@ -320,6 +324,7 @@ template <> struct Dist<M355_POISSON> {
 
 // ------------------------------------------------------------------------------------- binomial
 template <> struct Dist<M355_BINOMIAL> {
+  static constexpr int kBinned = 1;
   static constexpr int NP = 2;
   struct K {
     double n, p, lgn1, logp, log1mp;

@@ -530,6 +530,7 @@ template <> struct Dist<M355_LOGITNORMAL> {
 
 // --------------------------------------------------------------------------------- inversegamma
 template <> struct Dist<M355_INVERSEGAMMA> {
+  static constexpr int kBinned = 1;
   static constexpr int NP = 2;
   struct K { double alpha, beta, lga, c; };
   static M355_HD K derive(const double* p) {
@@ -559,6 +560,7 @@ template <> struct Dist<M355_INVERSEGAMMA> {
 
 // ----------------------------------------------------------------------------------- chisquared
 template <> struct Dist<M355_CHISQUARED> {
+  static constexpr int kBinned = 1;
   static constexpr int NP = 1;
   struct K { double nu, h, lgh, c; };  // h = nu/2
   static M355_HD K derive(const double* p) {
@@ -592,6 +594,7 @@ template <> struct Dist<M355_CHISQUARED> {
 
 // ---------------------------------------------------------------------- scaledinversechisquared
 template <> struct Dist<M355_SCALEDINVERSECHISQUARED> {
+  static constexpr int kBinned = 1;
   static constexpr int NP = 2;
   struct K { double nu, tau2, h, ht, lgh, c; };  // h = nu/2, ht = h*tau2
   static M355_HD K derive(const double* p) {
@@ -619,6 +622,7 @@ template <> struct Dist<M355_SCALEDINVERSECHISQUARED> {
 
 // --------------------------------------------------------------------------------- halfstudentt
 template <> struct Dist<M355_HALFSTUDENTT> {
+  static constexpr int kBinned = 1;
   static constexpr int NP = 2;
   struct K { double nu, sigma, logsigma, c, lbeta_h; };
   static M355_HD K derive(const double* p) {
@@ -663,6 +667,7 @@ template <> struct Dist<M355_HALFSTUDENTT> {
 
 // ----------------------------------------------------------------------------------- betascaled
 template <> struct Dist<M355_BETASCALED> {
+  static constexpr int kBinned = 1;
   static constexpr int NP = 4;
   static constexpr bool kLogTable = true;  // logpdf uses flog_tab
   struct K { double a, b, lo, hi, w, lbeta, c; };  // c = xlogy0(a+b-1, hi-lo) + betaln(a, b)

@@ -133,6 +133,7 @@ M355_DEV double negbin_sf(double x, const NegBinK& k) {
   return betainc_(kk + 1.0, k.n, 1.0 - k.p, lbeta_(kk + 1.0, k.n));
 }
 template <> struct Dist<M355_NEGATIVEBINOMIAL> {
+  static constexpr int kBinned = 1;
   static constexpr int NP = 2;
   using K = NegBinK;
   static M355_HD K derive(const double* p) { return negbin_derive(p[0], p[1]); }
@@ -154,6 +155,7 @@ template <> struct Dist<M355_NEGATIVEBINOMIAL> {
 
 // --------------------------------------------------------------------------------- betabinomial
 template <> struct Dist<M355_BETABINOMIAL> {
+  static constexpr int kBinned = 1;
   static constexpr int NP = 3;
   struct K { double n, a, b, c; };  // c: the x-independent gammaln terms
   static M355_HD K derive(const double* p) {
@@ -191,6 +193,7 @@ template <> struct Dist<M355_BETABINOMIAL> {
 
 // ------------------------------------------------------------------------------- hypergeometric
 template <> struct Dist<M355_HYPERGEOMETRIC> {
+  static constexpr int kBinned = 1;
   static constexpr int NP = 3;
   struct K { double N, k, n, lo, hi, lbNn, lgk1, lgNk1; };
   static M355_DEV double logbinom(double n, double k) { return (lgamma_(n + 1.0) - lgamma_(k + 1.0)) - lgamma_(n - k + 1.0); }
@@ -237,6 +240,7 @@ template <> struct Dist<M355_HYPERGEOMETRIC> {
 // Shared shape of zi_poisson.py / zi_binomial.py / zi_negativebinomial.py: BASE supplies the base
 // distribution's logpdf / cdf / sf and the zero probability.
 template <> struct Dist<M355_ZI_POISSON> {
+  static constexpr int kBinned = 1;
   static constexpr int NP = 2;
   struct K { double psi, logpsi, log_zero; Dist<M355_POISSON>::K b; };
   static M355_HD K derive(const double* p) {
@@ -272,6 +276,7 @@ template <> struct Dist<M355_ZI_POISSON> {
 };
 
 template <> struct Dist<M355_ZI_BINOMIAL> {
+  static constexpr int kBinned = 1;
   static constexpr int NP = 3;
   struct K { double psi, logpsi, log_zero; Dist<M355_BINOMIAL>::K b; };
   static M355_HD K derive(const double* p) {
@@ -305,6 +310,7 @@ template <> struct Dist<M355_ZI_BINOMIAL> {
 };
 
 template <> struct Dist<M355_ZI_NEGATIVEBINOMIAL> {
+  static constexpr int kBinned = 1;
   static constexpr int NP = 3;
   struct K { double psi, logpsi, log_zero; NegBinK b; };
   static M355_HD K derive(const double* p) {

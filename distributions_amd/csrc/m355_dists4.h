@@ -72,6 +72,7 @@ M355_DEV_HEAVY double owens_t_(double h, double a) {
 
 // ----------------------------------------------------------------------------------------- wald
 template <> struct Dist<M355_WALD> {
+  static constexpr int kBinned = 2;
   static constexpr int NP = 2;
   struct K { double mu, lam, c, mode, e2; };
   static M355_HD K derive(const double* p) {
@@ -109,6 +110,7 @@ template <> struct Dist<M355_WALD> {
 
 // ----------------------------------------------------------------------------------- exgaussian
 template <> struct Dist<M355_EXGAUSSIAN> {
+  static constexpr int kBinned = 2;
   static constexpr int NP = 3;
   struct K { double mu, sigma, nu, lognu, half_sn2, shift, ex; };  // shift = mu + sigma^2/nu; ex = (nu >= 0.05 sigma)
   static M355_HD K derive(const double* p) {
@@ -224,6 +226,7 @@ template <> struct Dist<M355_TRUNCATEDNORMAL> {
 
 // -------------------------------------------------------------------------------- skew_studentt
 template <> struct Dist<M355_SKEW_STUDENTT> {
+  static constexpr int kBinned = 1;
   static constexpr int NP = 4;
   struct K { double a, b, mu, sigma, ab, sqab, lbeta, c; };  // c = (a+b-1) log 2 + betaln + 0.5 log(a+b) + log sigma
   static M355_HD K derive(const double* p) {
@@ -271,6 +274,7 @@ template <> struct Dist<M355_SKEW_STUDENTT> {
 
 // ----------------------------------------------------------------------------------- skewnormal
 template <> struct Dist<M355_SKEWNORMAL> {
+  static constexpr int kBinned = 2;
   static constexpr int NP = 3;
   struct K { double mu, sigma, alpha, sqrt_tau, tau, c, mean; };  // tau = 1/sigma^2; c = log(tau/pi/2)
   static M355_HD K derive(const double* p) {
@@ -308,6 +312,7 @@ template <> struct Dist<M355_SKEWNORMAL> {
 // ive(0, kappa); for kappa >= 50 (normal approximation of the cdf, helper.py:365-368) ive(0, kappa) comes
 // from its asymptotic series.  Per element: helper.py:337-372 with the series coefficients read from K.
 template <> struct Dist<M355_VONMISES> {
+  static constexpr int kBinned = 2;
   static constexpr int NP = 2;
   static constexpr int kTerms = 50;
   struct K {
@@ -529,6 +534,7 @@ template <> struct Dist<M355_RICE> {
 // 500-point trapezoid of that density from 1e-10 to x (:124-134), evaluated per element (10^4 exp per cdf).  ppf:
 // its own clipped Newton iteration from a log-normal start (:149-184), 50 steps at most, per lane with early exit.
 template <> struct Dist<M355_POLYAGAMMA> {
+  static constexpr int kBinned = 1;
   static constexpr int NP = 2;
   static constexpr int kN = 20;
   static constexpr double kLower = 1e-10;  // polyagamma.py:15-16

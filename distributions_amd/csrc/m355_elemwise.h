@@ -21,6 +21,7 @@
 #include <hip/hip_runtime.h>
 
 #include "m355_dist_list.h"
+#include <cstdlib>
 #include <type_traits>
 
 #include "m355_dists4.h"
@@ -230,6 +231,123 @@ __global__ __launch_bounds__(kBlock) void k_periodic(const void* __restrict__ x,
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// k_binned: the special-function kernels (logcdf / logsf / ppf of gamma, beta, studentt, ...) are pinned at the
+// VALU issue limit with lane_util 0.25-0.5: lanes of a wavefront run series / continued fractions / Newton loops
+// of different lengths.  For fixed parameters the trip count is a smooth function of x, so each workgroup
+// sorts its tile by x in LDS (256 buckets over the tile's [min, max] of the order-preserving integer image of
+// the double, counting sort with LDS atomics), evaluates in sorted order -- a wavefront then holds 64 neighbours
+// in x, i.e. of similar cost -- and un-permutes through LDS, so global loads and stores stay coalesced and the
+// result is the same as k_scalar's, element for element.
+constexpr int kBinTile = 2048;  // elements per workgroup tile: 16 KiB x + 4 KiB index + 16 KiB results in LDS
+constexpr int kBinPer = kBinTile / kBlock;
+constexpr int kBuckets = 256;
+
+M355_DEV unsigned long long order_key(double x) {
+  const unsigned long long b = __builtin_bit_cast(unsigned long long, x);
+  return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+
+template <int D, int FN>
+__global__ __launch_bounds__(kBlock) void k_binned(const void* __restrict__ x, int xdt, void* __restrict__ out,
+                                                   int odt, long long n, const typename Dist<D>::K k) {
+  using DD = Dist<D>;
+  __shared__ double xs[kBinTile];
+  __shared__ double res[kBinTile];
+  __shared__ unsigned short idx[kBinTile];
+  __shared__ unsigned cnt[kBuckets];
+  __shared__ unsigned long long red_min[kBlock / 64], red_max[kBlock / 64];
+  if constexpr (uses_log_table<DD>::value) log_table_init();
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const long long ntiles = n / kBinTile;
+  for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const long long base = tile * kBinTile;
+    double v[kBinPer];
+    unsigned long long key[kBinPer];
+    unsigned long long kmin = ~0ull, kmax = 0ull;
+#pragma unroll
+    for (int j = 0; j < kBinPer; j += 2) load2<false>(x, xdt, base + (long long)(j / 2) * (kBlock * 2) + t * 2, v[j], v[j + 1]);
+#pragma unroll
+    for (int j = 0; j < kBinPer; ++j) {
+      key[j] = order_key(v[j]);
+      kmin = key[j] < kmin ? key[j] : kmin;
+      kmax = key[j] > kmax ? key[j] : kmax;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const unsigned long long a = __shfl_xor(kmin, o, 64), b = __shfl_xor(kmax, o, 64);
+      kmin = a < kmin ? a : kmin;
+      kmax = b > kmax ? b : kmax;
+    }
+    if (lane == 0) {
+      red_min[wave] = kmin;
+      red_max[wave] = kmax;
+    }
+    cnt[t] = 0u;  // kBuckets == kBlock
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < kBlock / 64; ++w) {
+      kmin = red_min[w] < kmin ? red_min[w] : kmin;
+      kmax = red_max[w] > kmax ? red_max[w] : kmax;
+    }
+    const unsigned long long span = kmax - kmin;
+    const int shift = span >> 8 ? 64 - 8 - __builtin_clzll(span) + 0 : 0;  // (span >> shift) < 256
+    unsigned bucket[kBinPer], rank[kBinPer];
+#pragma unroll
+    for (int j = 0; j < kBinPer; ++j) {
+      bucket[j] = (unsigned)((key[j] - kmin) >> shift);
+      rank[j] = atomicAdd(&cnt[bucket[j]], 1u);
+    }
+    __syncthreads();
+    // exclusive prefix sum of the 256 counters (one per thread): wave scan + wave totals
+    unsigned c = cnt[t], incl = c;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const unsigned up = __shfl_up(incl, o, 64);
+      if (lane >= o) incl += up;
+    }
+    __shared__ unsigned wave_tot[kBlock / 64];
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    unsigned off = 0;
+#pragma unroll
+    for (int w = 0; w < kBlock / 64; ++w) off += (w < wave) ? wave_tot[w] : 0u;
+    cnt[t] = off + incl - c;  // exclusive prefix
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < kBinPer; ++j) {
+      const unsigned slot = cnt[bucket[j]] + rank[j];
+      const int local = (j / 2) * (kBlock * 2) + t * 2 + (j & 1);
+      xs[slot] = v[j];
+      idx[slot] = (unsigned short)local;
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int j = 0; j < kBinPer; ++j) {
+      const int s_ = j * kBlock + t;
+      res[idx[s_]] = DD::template eval<FN>(xs[s_], k);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < kBinPer; j += 2) {
+      const int local = (j / 2) * (kBlock * 2) + t * 2;
+      store2<false>(out, odt, base + local, res[local], res[local + 1]);
+    }
+    __syncthreads();
+  }
+  for (long long i = ntiles * kBinTile + (long long)blockIdx.x * kBlock + t; i < n; i += (long long)gridDim.x * kBlock)
+    store1(out, odt, i, DD::template eval<FN>(load1(x, xdt, i), k));
+}
+
+// Dist<D>::kBinned = 1: every function but logpdf / pdf goes through k_binned; = 2: only ppf / isf (families whose
+// cdf is closed-form but whose quantile is a Newton iteration).
+template <class T, class = void> struct binning_mode { static constexpr int value = 0; };
+template <class T> struct binning_mode<T, std::void_t<decltype(T::kBinned)>> { static constexpr int value = T::kBinned; };
+template <class T, int FN> constexpr bool bin_this() {
+  constexpr int m = binning_mode<T>::value;
+  return (m == 1 && FN != M355_LOGPDF && FN != M355_PDF) || (m == 2 && (FN == M355_PPF || FN == M355_ISF));
+}
+
 struct GenericOps {
   DevOperand x;
   DevOperand p[kMaxParams];
@@ -277,6 +395,12 @@ __global__ __launch_bounds__(kBlock) void k_generic(GenericOps ops, void* __rest
 template <class T, class = void> struct device_derive : std::false_type {};
 template <class T> struct device_derive<T, std::void_t<decltype(T::kDeviceDerive)>> : std::true_type {};
 
+// M355_NO_BINNING=1 in the environment sends the divergent functions through k_scalar (A/B measurements)
+inline bool binning_disabled() {
+  static const bool off = [] { const char* e = getenv("M355_NO_BINNING"); return e && e[0] == '1'; }();
+  return off;
+}
+
 inline bool aligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; }
 
 // Host-side selection of the kernel for one (dist, fn); returns a hipError_t as int.
@@ -318,6 +442,15 @@ template <int D, int FN, bool REDUCE> int launch_fn(const LaunchArgs& a) {
       // parameter-only constants once, on the host; they reach the kernel as arguments (SGPRs)
       const double pp[kMaxParams] = {a.p[0].scalar, a.p[1].scalar, a.p[2].scalar, a.p[3].scalar};
       const typename DD::K k = DD::derive(pp);
+      if constexpr (!REDUCE && bin_this<DD, FN>()) {
+        if (n >= 4 * kBinTile && !binning_disabled()) {
+          const long long bt = n / kBinTile;
+          const int bb = (int)(bt > kMaxBlocks ? kMaxBlocks : bt);
+          hipLaunchKernelGGL((k_binned<D, FN>), dim3(bb), dim3(kBlock), 0, a.stream, a.x.ptr, a.x.dtype, a.out,
+                             a.out_dtype, n, k);
+          return (int)hipGetLastError();
+        }
+      }
       if (f64io) {
         if constexpr (kFastIO)
           hipLaunchKernelGGL((k_scalar<D, FN, REDUCE, true>), dim3(blocks), dim3(kBlock), 0, a.stream,

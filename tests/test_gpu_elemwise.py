@@ -310,3 +310,30 @@ def test_polyagamma(gpu, h, z):
     assert stats.kstest(x[:4000], lambda v: R.TABLE["polyagamma_cdf"](v, h, z)).pvalue > 1e-3
     mean = h / 4.0 if z == 0 else h / (2 * z) * np.tanh(z / 2)
     assert abs(x.mean() - mean) <= 3e-2 * mean
+
+
+@pytest.mark.parametrize("name, fn, params", [("gamma", "logcdf", (2.5, 1.3)), ("beta", "ppf", (2.0, 5.0)),
+                                               ("studentt", "logsf", (5.0, 0.0, 2.0)), ("poisson", "cdf", (7.5,)),
+                                               ("betabinomial", "cdf", (20.0, 0.5, 0.5)), ("wald", "ppf", (2.0, 10.0))])
+def test_binned_kernel_equals_scalar_kernel(gpu, name, fn, params):
+    """k_binned (LDS sort of each 2048-element tile by x, evaluation in sorted order, un-permuted stores) returns
+    bit for bit what k_scalar returns: large inputs take the binned path, slices below 4 tiles the plain one."""
+    rng = np.random.default_rng(51)
+    n = 6 * 2048 + 777  # a ragged tail after the last full tile
+    if fn in ("ppf", "isf"):
+        x = rng.uniform(0, 1, n)
+        x[:7] = [0.0, 1.0, -0.5, 1.5, np.nan, 0.5, 1e-300]
+    elif name in ("poisson", "betabinomial"):
+        x = rng.integers(-2, 30, n).astype(np.float64)
+    else:
+        x = np.abs(rng.standard_cauchy(n)) if name != "studentt" else rng.standard_cauchy(n) * 3
+        x[:6] = [0.0, np.inf, -np.inf, np.nan, -1.0, 1e-300]
+    if name == "beta" and fn not in ("ppf", "isf"):
+        x = rng.uniform(-0.1, 1.1, n)
+    m = mod(name)
+    big = getattr(m, fn)(x, *params)
+    parts = np.concatenate([getattr(m, fn)(x[i:i + 4096], *params) for i in range(0, n, 4096)])
+    assert np.array_equal(big, parts, equal_nan=True)
+    if name == "poisson":  # int64 observations through the binned path
+        k = x.astype(np.int64)
+        assert np.array_equal(getattr(m, fn)(k, *params), big, equal_nan=True)
