@@ -534,7 +534,6 @@ template <> struct Dist<M355_RICE> {
 // 500-point trapezoid of that density from 1e-10 to x (:124-134), evaluated per element (10^4 exp per cdf).  ppf:
 // its own clipped Newton iteration from a log-normal start (:149-184), 50 steps at most, per lane with early exit.
 template <> struct Dist<M355_POLYAGAMMA> {
-  static constexpr int kBinned = 1;
   static constexpr int NP = 2;
   static constexpr int kN = 20;
   static constexpr double kLower = 1e-10;  // polyagamma.py:15-16

@@ -242,6 +242,7 @@ __global__ __launch_bounds__(kBlock) void k_periodic(const void* __restrict__ x,
 constexpr int kBinTile = 2048;  // elements per workgroup tile: 16 KiB x + 4 KiB index + 16 KiB results in LDS
 constexpr int kBinPer = kBinTile / kBlock;
 constexpr int kBuckets = 256;
+constexpr int kBinMinTiles = 256;  // below ~5e5 elements the 1024-element tiles of k_scalar fill the 256 CUs better
 
 M355_DEV unsigned long long order_key(double x) {
   const unsigned long long b = __builtin_bit_cast(unsigned long long, x);
@@ -443,7 +444,7 @@ template <int D, int FN, bool REDUCE> int launch_fn(const LaunchArgs& a) {
       const double pp[kMaxParams] = {a.p[0].scalar, a.p[1].scalar, a.p[2].scalar, a.p[3].scalar};
       const typename DD::K k = DD::derive(pp);
       if constexpr (!REDUCE && bin_this<DD, FN>()) {
-        if (n >= 4 * kBinTile && !binning_disabled()) {
+        if (n >= (long long)kBinMinTiles * kBinTile && !binning_disabled()) {
           const long long bt = n / kBinTile;
           const int bb = (int)(bt > kMaxBlocks ? kMaxBlocks : bt);
           hipLaunchKernelGGL((k_binned<D, FN>), dim3(bb), dim3(kBlock), 0, a.stream, a.x.ptr, a.x.dtype, a.out,
