@@ -235,19 +235,15 @@ __global__ __launch_bounds__(kBlock) void k_periodic(const void* __restrict__ x,
 // k_binned: the special-function kernels (logcdf / logsf / ppf of gamma, beta, studentt, ...) are pinned at the
 // VALU issue limit with lane_util 0.25-0.5: lanes of a wavefront run series / continued fractions / Newton loops
 // of different lengths.  For fixed parameters the trip count is a smooth function of x, so each workgroup
-// sorts its tile by x in LDS (256 buckets over the tile's [min, max] of the order-preserving integer image of
-// the double, counting sort with LDS atomics), evaluates in sorted order -- a wavefront then holds 64 neighbours
+// sorts its tile by x in LDS (256 buckets over the tile's range of the key sign(x) (1 + |x| / mean|x|) read as an
+// ordered integer: linear in x in the bulk on both sides of zero, logarithmic in the tails; counting sort with LDS
+// atomics), evaluates in sorted order -- a wavefront then holds 64 neighbours
 // in x, i.e. of similar cost -- and un-permutes through LDS, so global loads and stores stay coalesced and the
 // result is the same as k_scalar's, element for element.
 constexpr int kBinTile = 2048;  // elements per workgroup tile: 16 KiB x + 4 KiB index + 16 KiB results in LDS
 constexpr int kBinPer = kBinTile / kBlock;
 constexpr int kBuckets = 256;
 constexpr int kBinMinTiles = 256;  // below ~5e5 elements the 1024-element tiles of k_scalar fill the 256 CUs better
-
-M355_DEV unsigned long long order_key(double x) {
-  const unsigned long long b = __builtin_bit_cast(unsigned long long, x);
-  return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
-}
 
 template <int D, int FN>
 __global__ __launch_bounds__(kBlock) void k_binned(const void* __restrict__ x, int xdt, void* __restrict__ out,
@@ -258,6 +254,7 @@ __global__ __launch_bounds__(kBlock) void k_binned(const void* __restrict__ x, i
   __shared__ unsigned short idx[kBinTile];
   __shared__ unsigned cnt[kBuckets];
   __shared__ unsigned long long red_min[kBlock / 64], red_max[kBlock / 64];
+  __shared__ double red_s[kBlock / 64], red_c[kBlock / 64];
   if constexpr (uses_log_table<DD>::value) log_table_init();
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const long long ntiles = n / kBinTile;
@@ -268,9 +265,41 @@ __global__ __launch_bounds__(kBlock) void k_binned(const void* __restrict__ x, i
     unsigned long long kmin = ~0ull, kmax = 0ull;
 #pragma unroll
     for (int j = 0; j < kBinPer; j += 2) load2<false>(x, xdt, base + (long long)(j / 2) * (kBlock * 2) + t * 2, v[j], v[j + 1]);
+    // scale of the tile: mean |x| over its finite elements
+    double sabs = 0.0, cfin = 0.0;
 #pragma unroll
     for (int j = 0; j < kBinPer; ++j) {
-      key[j] = order_key(v[j]);
+      const double av = __builtin_fabs(v[j]);
+      const bool fin = av < kInf;
+      sabs += fin ? av : 0.0;
+      cfin += fin ? 1.0 : 0.0;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      sabs += __shfl_xor(sabs, o, 64);
+      cfin += __shfl_xor(cfin, o, 64);
+    }
+    if (lane == 0) {
+      red_s[wave] = sabs;
+      red_c[wave] = cfin;
+    }
+    __syncthreads();
+    sabs = 0.0;
+    cfin = 0.0;
+#pragma unroll
+    for (int w = 0; w < kBlock / 64; ++w) {
+      sabs += red_s[w];
+      cfin += red_c[w];
+    }
+    const double inv_scale = (sabs > 0.0 && cfin > 0.0) ? cfin / sabs : 1.0;
+    // sort key: sign(x) * (1 + |x| / scale) read as an ordered integer -- linear in x inside the bulk (one binade
+    // on each side of zero), logarithmic in the tails; +-inf / NaN are clamped so that they do not stretch the range
+#pragma unroll
+    for (int j = 0; j < kBinPer; ++j) {
+      double tt = __builtin_fabs(v[j]) * inv_scale;
+      tt = tt < 1048576.0 ? tt : ((tt == tt) ? 1048576.0 : 0.0);
+      const long long mag = (long long)(__builtin_bit_cast(unsigned long long, 1.0 + tt) - 0x3ff0000000000000ull);
+      key[j] = (unsigned long long)((v[j] < 0.0 ? -mag : mag) + (1ll << 62));  // contiguous across zero
       kmin = key[j] < kmin ? key[j] : kmin;
       kmax = key[j] > kmax ? key[j] : kmax;
     }

@@ -404,38 +404,47 @@ M355_DEV_HEAVY double betainc_pseries(double a, double b, double x, double lbeta
   return (tl < kMinLog) ? 0.0 : exp_(tl);
 }
 
-// Continued fraction DLMF 8.17.22 by the modified Lentz algorithm; converges fast for
-// x < (a+1)/(a+b+2).  Returns the fraction value (without the x^a(1-x)^b/(a B) prefactor).
+// Continued fraction DLMF 8.17.22, x < (a+1)/(a+b+2), by the forward recurrence of its numerators and
+// denominators A_k = b_k A_{k-1} + a_k A_{k-2} after the equivalence transformation that clears the partial
+// numerators' denominators (a_k' = D_{k-1} N_k, b_k' = D_k for a_k = N_k / D_k, b_k = 1): no division inside a step,
+// one per pair of steps for the convergence test, renormalised by a power of two after every pair.  Returns the fraction
+// value (without the x^a(1-x)^b/(a B) prefactor).
 M355_DEV_HEAVY double betainc_cf(double a, double b, double x) {
-  constexpr double tiny = 1e-300;
-  const double qab = a + b, qap = a + 1.0, qam = a - 1.0;
-  double c = 1.0;
-  double d = 1.0 - fdiv(qab * x, qap);
-  if (__builtin_fabs(d) < tiny) d = tiny;
-  d = rcp(d);
-  double h = d;
+  const double qab = a + b, qam = a - 1.0;
+  // A_{-1} = 1, B_{-1} = 0, A_0 = b_0 = 1, B_0 = 1 for the fraction 1 / (1 + d_1 / (1 + d_2 / (1 + ...))):
+  // evaluate f = 1 + d_1/(1 + d_2/(...)) and return 1 / f
+  double Am = 1.0, Bm = 0.0, A = 1.0, B = 1.0;  // (A_{k-2}, B_{k-2}), (A_{k-1}, B_{k-1}) of f
+  double Dprev = 1.0;
+  double ans = 1.0;
   for (int m = 1; m < kMaxIter; ++m) {
     M355_ITER();
-    const double dm = (double)m;
-    const double m2 = 2.0 * dm;
-    double aa = fdiv(dm * (b - dm) * x, (qam + m2) * (a + m2));
-    d = 1.0 + aa * d;
-    if (__builtin_fabs(d) < tiny) d = tiny;
-    c = 1.0 + fdiv(aa, c);
-    if (__builtin_fabs(c) < tiny) c = tiny;
-    d = rcp(d);
-    h *= d * c;
-    aa = -fdiv((a + dm) * (qab + dm) * x, (a + m2) * (qap + m2));
-    d = 1.0 + aa * d;
-    if (__builtin_fabs(d) < tiny) d = tiny;
-    c = 1.0 + fdiv(aa, c);
-    if (__builtin_fabs(c) < tiny) c = tiny;
-    d = rcp(d);
-    const double del = d * c;
-    h *= del;
-    if (__builtin_fabs(del - 1.0) <= 2.0 * kEps) break;
+    const double dm = (double)m, m2 = 2.0 * dm;
+    // d_{2m-1} = -(a+m-1)(a+b+m-1) x / ((a+2m-2)(a+2m-1)), d_{2m} = m (b-m) x / ((a+2m-1)(a+2m))
+    const double N1 = -(qam + dm) * (qab + dm - 1.0) * x, D1 = (qam + m2 - 1.0) * (qam + m2);
+    double t = Dprev * N1;
+    double An = D1 * A + t * Am, Bn = D1 * B + t * Bm;
+    Am = A; Bm = B; A = An; B = Bn;
+    const double N2 = dm * (b - dm) * x, D2 = (qam + m2) * (a + m2);
+    t = D1 * N2;
+    An = D2 * A + t * Am;
+    Bn = D2 * B + t * Bm;
+    Am = A; Bm = B; A = An; B = Bn;
+    Dprev = D2;
+    // renormalise by the exact power of two that brings |A| + |B| to [1/2, 1): the D_k grow like (a + 2m)^2
+    const double mag = __builtin_fabs(A) + __builtin_fabs(B);
+    if (mag > 0.0 && mag < kInf) {
+      const int e = hw_frexp_exp(mag);
+      const double sc = __builtin_bit_cast(double, (unsigned long long)(1023 - e) << 52);
+      A *= sc; B *= sc; Am *= sc; Bm *= sc;
+    }
+    if (B != 0.0) {
+      const double r = fdiv(A, B);
+      const bool done = __builtin_fabs(ans - r) <= 2.0 * kEps * __builtin_fabs(r);
+      ans = r;
+      if (done) break;
+    }
   }
-  return h;
+  return rcp(ans);
 }
 
 // Regularised incomplete beta I_x(a,b) (pt.betainc).  `y` must be 1-x; lbeta = betaln(a,b).
