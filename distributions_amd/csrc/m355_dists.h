@@ -98,6 +98,29 @@ template <> struct Dist<M355_GAMMA> {
     const double r = (t - x * k.beta) + k.c;
     return (x < 0.0) ? -kInf : r;
   }
+  // sum of logpdf over a thread's elements (k_scalar with REDUCE): sum_i log x_i as a LogProd.
+  // Same value as summing logpdf() within the rounding of the sum itself; x <= 0, subnormal, inf and NaN
+  // take logpdf() and add into `exc`, which carries -inf / NaN exactly as the plain sum would.
+  struct SumAcc {
+    LogProd px;
+    double sx = 0.0, exc = 0.0;
+    int cnt = 0;
+  };
+  static M355_DEV bool sum_ok(const K& k) { return __builtin_fabs(k.am1) <= kSumAccMaxCoef; }
+  static M355_DEV void sum_add(SumAcc& s, double x, const K& k) {
+    if ((x >= kMinNormal) & (x < kInf)) {
+      s.px.mul(x);
+      s.sx += x;
+      ++s.cnt;
+    } else {
+      s.exc += logpdf(x, k);
+    }
+  }
+  static M355_DEV void sum_renorm(SumAcc& s) { s.px.renorm(); }
+  static M355_DEV double sum_finish(const SumAcc& s, const K& k) {
+    const double reg = (k.am1 * s.px.log() - k.beta * s.sx) + (double)s.cnt * k.c;
+    return reg + s.exc;
+  }
   // gamma.py:65-74
   static M355_DEV double logcdf(double x, const K& k) {
     const double xb = x * k.beta;
@@ -161,6 +184,33 @@ template <> struct Dist<M355_BETA> {
     const double r = t - (0.0 + k.lbeta);
     return ((x < 0.0) | (x > 1.0)) ? -kInf : r;
   }
+  // sum of logpdf (see Dist<M355_GAMMA>::SumAcc): sum log x and sum log(1 - x) as LogProds; for
+  // min_normal <= x < 1 the complement 1 - x is in [2^-53, 1), normal.
+  struct SumAcc {
+    LogProd px, pc;
+    double exc = 0.0;
+    int cnt = 0;
+  };
+  static M355_DEV bool sum_ok(const K& k) {
+    return (__builtin_fabs(k.am1) <= kSumAccMaxCoef) & (__builtin_fabs(k.bm1) <= kSumAccMaxCoef);
+  }
+  static M355_DEV void sum_add(SumAcc& s, double x, const K& k) {
+    if ((x >= kMinNormal) & (x < 1.0)) {
+      s.px.mul(x);
+      s.pc.mul(1.0 - x);
+      ++s.cnt;
+    } else {
+      s.exc += logpdf(x, k);
+    }
+  }
+  static M355_DEV void sum_renorm(SumAcc& s) {
+    s.px.renorm();
+    s.pc.renorm();
+  }
+  static M355_DEV double sum_finish(const SumAcc& s, const K& k) {
+    const double reg = (k.am1 * s.px.log() + k.bm1 * s.pc.log()) - (double)s.cnt * k.lbeta;
+    return reg + s.exc;
+  }
   // beta.py:90-99
   static M355_DEV double logcdf(double x, const K& k) {
     if (x < 0.0) return -kInf;
@@ -215,6 +265,32 @@ template <> struct Dist<M355_STUDENTT> {
     if (k.nu > 1e5) return normal_logcdf_z((x - k.mu) / k.sigma);
     const double d = x - k.mu;
     return k.c - k.hnp1 * flog1p_tab(d * d * k.inv_s2nu);
+  }
+  // sum of logpdf (see Dist<M355_GAMMA>::SumAcc): sum log1p(w_i) = log prod (1 + w_i) + the rounding of
+  // 1 + w_i recovered to first order (as flog1p_tab does), summed on the side.
+  struct SumAcc {
+    LogProd pu;
+    double corr = 0.0, exc = 0.0;
+    int cnt = 0;
+  };
+  static M355_DEV bool sum_ok(const K& k) { return (k.hnp1 <= kSumAccMaxCoef) & !(k.nu > 1e5); }
+  static M355_DEV void sum_add(SumAcc& s, double x, const K& k) {
+    const double d = x - k.mu;
+    const double w = d * d * k.inv_s2nu;
+    if (w < 0x1p1000) {
+      const double u = 1.0 + w;
+      const double c = w - (u - 1.0);
+      s.corr += (w < 0.5) ? c * (2.0 - u) : 0.0;
+      s.pu.mul(u);
+      ++s.cnt;
+    } else {
+      s.exc += logpdf(x, k);
+    }
+  }
+  static M355_DEV void sum_renorm(SumAcc& s) { s.pu.renorm(); }
+  static M355_DEV double sum_finish(const SumAcc& s, const K& k) {
+    const double reg = (double)s.cnt * k.c - k.hnp1 * (s.pu.log() + s.corr);
+    return reg + s.exc;
   }
   // studentt.py:100-105.  The nu > 1e5 arm is normal.CDF(z, mu, sigma) on the already
   // standardised z (mis-import studentt.py:6); reproduced as is (quirk Q1).

@@ -121,6 +121,12 @@ M355_DEV double block_reduce_sum(double v) {
 template <class T, class = void> struct uses_log_table : std::false_type {};
 template <class T> struct uses_log_table<T, std::void_t<decltype(T::kLogTable)>> : std::true_type {};
 
+// Dist<D>::SumAcc: the sum of logpdf over a thread's elements has a cheaper form than summing logpdf()
+// (sums of logarithms as products, m355_math.h LogProd); sum_ok(K) says whether it applies to these parameters.
+template <class T, class = void> struct has_sum_acc : std::false_type {};
+template <class T> struct has_sum_acc<T, std::void_t<typename T::SumAcc>> : std::true_type {};
+constexpr int kRenormEvery = 64;  // tiles (4 elements per thread each) between LogProd renormalisations
+
 template <int D, int FN, bool REDUCE, bool F64IO>
 __global__ __launch_bounds__(kBlock) void k_scalar(const void* __restrict__ x, int xdt,
                                                    void* __restrict__ out, int odt, long long n,
@@ -130,6 +136,33 @@ __global__ __launch_bounds__(kBlock) void k_scalar(const void* __restrict__ x, i
   if constexpr (uses_log_table<DD>::value) log_table_init();
   const long long ntiles = n / kTile;
   double acc = 0.0;
+  if constexpr (REDUCE && FN == M355_LOGPDF && has_sum_acc<DD>::value) {
+    if (DD::sum_ok(k)) {  // uniform: parameters are kernel arguments
+      typename DD::SumAcc s;
+      int since = 0;
+      for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const long long base = tile * kTile + threadIdx.x * kVec;
+        double v[kUnroll][kVec];
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) load2<F64IO>(x, xdt, base + u * (kBlock * kVec), v[u][0], v[u][1]);
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) {
+          DD::sum_add(s, v[u][0], k);
+          DD::sum_add(s, v[u][1], k);
+        }
+        if (++since == kRenormEvery) {
+          since = 0;
+          DD::sum_renorm(s);
+        }
+      }
+      for (long long i = ntiles * kTile + (long long)blockIdx.x * kBlock + threadIdx.x; i < n;
+           i += (long long)gridDim.x * kBlock)
+        DD::sum_add(s, load1(x, xdt, i), k);
+      acc = block_reduce_sum(DD::sum_finish(s, k));
+      if (threadIdx.x == 0) partials[blockIdx.x] = acc;
+      return;
+    }
+  }
   for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const long long base = tile * kTile + threadIdx.x * kVec;
     double v[kUnroll][kVec];

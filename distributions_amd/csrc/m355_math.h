@@ -253,6 +253,41 @@ M355_HD double flog1p_tab(double w) {
   return flog_tab(u) + corr;
 }
 
+// Sum of logarithms carried as a product: sum_i log(v_i) = log(prod_i m_i) + ln2 * sum_i e_i with
+// v_i = m_i 2^e_i, m_i in [sqrt(1/2), sqrt(2)) (the split of flog_tab: v ~ 1 gives e = 0, so nothing cancels
+// between the two parts).  One fp64 multiply and five integer ops per term instead of a logarithm
+// (~14-25 op equivalents); the logarithm is taken once per thread.  Every multiply rounds at 2^-53 relative,
+// i.e. an absolute error per term of the size of one rounded logarithm of a value of order 1 - callers use it
+// only where the coefficient of the logarithm is moderate (see Dist<>::SumAcc).  Terms must be positive,
+// finite and normal (everything else goes through the elementwise function); renorm() at least every
+// 1024 terms keeps the running product inside the exponent range.
+struct LogProd {
+  double m = 1.0;  // product of the re-based mantissas
+  int e = 0;       // sum of the exponents
+  M355_HD void mul(double v) {
+    const unsigned long long bits = __builtin_bit_cast(unsigned long long, v);
+    const unsigned hx = (unsigned)(bits >> 32) + (0x3ff00000u - 0x3fe6a09eu);
+    e += (int)(hx >> 20) - 0x3ff;
+    m *= __builtin_bit_cast(double, ((unsigned long long)((hx & 0x000fffffu) + 0x3fe6a09eu) << 32) | (bits & 0xffffffffull));
+  }
+  M355_HD void renorm() {
+    const double t = m;
+    m = 1.0;
+    mul(t);
+  }
+  M355_HD double log() const {
+    LogProd c = *this;
+    c.renorm();
+    const double ef = (double)c.e;
+    return __builtin_fma(ef, kLn2Hi, __builtin_fma(ef, kLn2Lo, flog(c.m)));
+  }
+};
+// the smallest normal double: below it LogProd::mul does not apply
+constexpr double kMinNormal = 0x1p-1022;
+// largest |coefficient of the logarithm| for which the sum-logp kernels use LogProd: above it the absolute
+// rounding of the product (coef * 1e-16 per term) is not negligible next to terms of order 1
+constexpr double kSumAccMaxCoef = 1024.0;
+
 // pytensor.tensor.xlogx.xlogy0 given log(y): 0 where a == 0.
 M355_HD double xlogy0_l(double a, double logy) { return a == 0.0 ? 0.0 : a * logy; }
 

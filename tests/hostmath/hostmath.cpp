@@ -39,6 +39,29 @@ extern "C" int hm_eval(int dist, int fn, long n, const double* x, const double* 
   return -1;
 }
 
+// Dist<D>::SumAcc (sum of logpdf with the logarithms carried as products), one "thread" over all n elements,
+// renormalised every 256 elements as k_scalar does.  Returns 0 and the sum, or 1 if sum_ok() declines.
+template <int D> static int run_sum_acc(long n, const double* x, const double* p, double* out) {
+  using DD = Dist<D>;
+  const auto k = DD::derive(p);
+  if (!DD::sum_ok(k)) return 1;
+  typename DD::SumAcc s;
+  for (long i = 0; i < n; ++i) {
+    DD::sum_add(s, x[i], k);
+    if ((i & 255) == 255) DD::sum_renorm(s);
+  }
+  *out = DD::sum_finish(s, k);
+  return 0;
+}
+extern "C" int hm_sum_acc(int dist, long n, const double* x, const double* p, double* out) {
+  switch (dist) {
+    case M355_GAMMA: return run_sum_acc<M355_GAMMA>(n, x, p, out);
+    case M355_BETA: return run_sum_acc<M355_BETA>(n, x, p, out);
+    case M355_STUDENTT: return run_sum_acc<M355_STUDENTT>(n, x, p, out);
+  }
+  return -1;
+}
+
 extern "C" void hm_log(long n, const double* x, double* out) { for (long i = 0; i < n; ++i) out[i] = flog(x[i]); }
 extern "C" void hm_log1p(long n, const double* x, double* out) { for (long i = 0; i < n; ++i) out[i] = flog1p(x[i]); }
 extern "C" void hm_gammainc(long n, const double* a, const double* x, double* out) {

@@ -170,6 +170,48 @@ def test_sumlogp(gpu):
     assert abs(gamma.sum_logpdf(xr, a_row, 1.1) - math.fsum(terms.ravel())) <= 1e-12 * float(np.abs(terms).sum())
 
 
+def test_sumlogp_product_form_edges(gpu):
+    """The scalar-parameter sum-logp kernel carries sums of logarithms as products (Dist<>::SumAcc): zeros,
+    subnormals, out-of-support points, inf and NaN must give what summing the elementwise results gives, and
+    parameters above the coefficient limit (plain summation) the same value within the tolerance."""
+    from distributions_amd import beta, gamma, studentt
+
+    rng = np.random.default_rng(31)
+    n = 1_500_007
+    base = {"gamma": (gamma, (2.5, 1.3), rng.gamma(2.5, 1.0, n)), "beta": (beta, (2.0, 5.0), rng.beta(2, 5, n)),
+            "studentt": (studentt, (5.0, 0.0, 2.0), 2 * rng.standard_t(5, n))}
+    for name, extra in (("gamma", []), ("gamma", [0.0]), ("gamma", [-1.0]), ("gamma", [5e-324, 1e-310]), ("gamma", [np.inf]),
+                        ("gamma", [np.nan]), ("beta", []), ("beta", [0.0]), ("beta", [1.0]), ("beta", [1.5]), ("beta", [1e-320]),
+                        ("beta", [np.nan, -1.0]), ("studentt", []), ("studentt", [np.inf]), ("studentt", [1e200, -1e200]),
+                        ("studentt", [np.nan])):
+        m, params, x0 = base[name]
+        x = x0.copy()
+        for j, e in enumerate(extra):
+            x[(j + 1) * 333_331] = e
+        with np.errstate(all="ignore"):
+            terms = R.TABLE[f"{name}_logpdf"](x, *params)
+            exp = float(np.sum(terms))
+        got = m.sum_logpdf(x, *params)
+        if math.isfinite(exp):
+            assert abs(got - math.fsum(terms)) <= 1e-12 * float(np.sum(np.abs(terms))), (name, extra, got, exp)
+        else:
+            assert (math.isnan(exp) and math.isnan(got)) or got == exp, (name, extra, got, exp)
+    # gamma(alpha = 1): x = 0 contributes 0, not 0 * -inf (quirk Q2)
+    x = np.concatenate([rng.gamma(1.0, 1.0, 100_000), [0.0]])
+    t = R.gamma_logpdf(x, 1.0, 2.0)
+    assert abs(gamma.sum_logpdf(x, 1.0, 2.0) - math.fsum(t)) <= 1e-12 * float(np.abs(t).sum())
+    # above the coefficient limit the kernel sums logpdf() itself
+    for m, name, params, x in ((gamma, "gamma", (5000.0, 2.0), rng.gamma(5000.0, 0.5, 200_001)),
+                               (beta, "beta", (3000.0, 2.0), rng.beta(3000, 2, 200_001)),
+                               (studentt, "studentt", (4000.0, 1.0, 2.0), 1 + 2 * rng.standard_t(4000, 200_001))):
+        t = R.TABLE[f"{name}_logpdf"](x, *params)
+        assert abs(m.sum_logpdf(x, *params) - math.fsum(t)) <= 1e-12 * float(np.abs(t).sum()), name
+    # just under the limit, data where log x is tiny (x ~ 1 - 1e-3)
+    x = rng.beta(1000, 1, 1_000_003)
+    t = R.beta_logpdf(x, 1000.0, 1.0)
+    assert abs(beta.sum_logpdf(x, 1000.0, 1.0) - math.fsum(t)) <= 1e-12 * float(np.abs(t).sum())
+
+
 def test_full_size_1e8_sampled(gpu):
     """BASELINE.json's full size: N = 1e8 fp64, every 97th element checked against the oracle."""
     import torch

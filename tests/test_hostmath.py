@@ -317,3 +317,74 @@ def test_host_polyagamma_vs_oracle(hostlib, h, z):
         got = getattr(ns, fn)(xs, h, z)
         ok = _close(got, exp) | H.cancellation_ok(fn, got, exp)
         assert np.all(ok), (fn, h, z, xs[~ok][:5], got[~ok][:5], exp[~ok][:5])
+
+
+def _host_sum_acc(lib, name, x, params):
+    x = np.ascontiguousarray(np.asarray(x, dtype=np.float64))
+    p = np.ascontiguousarray(np.asarray(list(params) + [0.0] * 4, dtype=np.float64)[:4])
+    out = ctypes.c_double()
+    rc = lib.hm_sum_acc(DIST[name], ctypes.c_long(x.size), _ptr(x), _ptr(p), ctypes.byref(out))
+    return rc, out.value
+
+
+_SUM_ACC_CASES = [
+    ("gamma", (2.5, 1.3), lambda r, n: r.gamma(2.5, 1 / 1.3, n)),
+    ("gamma", (0.01, 10.0), lambda r, n: np.maximum(r.gamma(0.01, 0.1, n), 1e-300)),
+    ("gamma", (1.0, 1.0), lambda r, n: r.gamma(1.0, 1.0, n)),
+    ("gamma", (900.0, 3.0), lambda r, n: r.gamma(900.0, 1 / 3.0, n)),
+    ("beta", (2.0, 5.0), lambda r, n: r.beta(2, 5, n)),
+    ("beta", (0.5, 0.5), lambda r, n: np.clip(r.beta(0.5, 0.5, n), 1e-300, 1 - 1e-16)),
+    ("beta", (800.0, 1.0), lambda r, n: r.beta(800, 1, n)),       # x just below 1: log x ~ -1e-3
+    ("beta", (1.0, 1.0), lambda r, n: r.uniform(0, 1, n)),
+    ("studentt", (5.0, 0.0, 2.0), lambda r, n: 2 * r.standard_t(5, n)),
+    ("studentt", (1.0, 3.0, 0.01), lambda r, n: 3 + 0.01 * r.standard_t(1, n)),   # cauchy tails: 1 + w up to 1e30
+    ("studentt", (2000.0, 0.0, 1.0), lambda r, n: 1e-9 * r.normal(size=n)),      # w ~ 1e-21: the side sum carries it
+]
+
+
+@pytest.mark.parametrize("name, params, draw", _SUM_ACC_CASES, ids=[f"{c[0]}-{c[1]}" for c in _SUM_ACC_CASES])
+def test_host_sum_acc_vs_fsum(hostlib, name, params, draw):
+    """Dist<>::SumAcc (sum of logpdf with sums of logarithms carried as products, csrc/m355_math.h LogProd)
+    against math.fsum of the oracle's logpdf terms: 1e-12 * sum |term|."""
+    import math
+
+    rng = np.random.default_rng(77)
+    for n in (1, 7, 100_003):
+        x = draw(rng, n)
+        terms = R.TABLE[f"{name}_logpdf"](x, *params)
+        rc, got = _host_sum_acc(hostlib, name, x, params)
+        assert rc == 0
+        assert abs(got - math.fsum(terms)) <= 1e-12 * float(np.sum(np.abs(terms))), (name, params, n, got, math.fsum(terms))
+
+
+def test_host_sum_acc_exceptional_elements(hostlib):
+    """Zeros, subnormals, out-of-support points, inf and NaN leave the product and add logpdf() itself: the sum is
+    -inf / +inf / NaN exactly where the plain sum of the elementwise results is."""
+    import math
+
+    rng = np.random.default_rng(78)
+    base = {"gamma": ((2.5, 1.3), rng.gamma(2.5, 1.0, 1000)), "beta": ((2.0, 5.0), rng.beta(2, 5, 1000)),
+            "studentt": ((5.0, 0.0, 2.0), rng.standard_t(5, 1000))}
+    for name, extra in (("gamma", [0.0]), ("gamma", [-1.0]), ("gamma", [5e-324, 1e-310]), ("gamma", [np.inf]), ("gamma", [np.nan]),
+                        ("beta", [0.0]), ("beta", [1.0]), ("beta", [1.5]), ("beta", [1e-320]), ("beta", [np.nan, -1.0]),
+                        ("studentt", [np.inf]), ("studentt", [1e200, -1e200]), ("studentt", [np.nan])):
+        params, x0 = base[name]
+        x = np.concatenate([x0[:500], extra, x0[500:]])
+        with np.errstate(all="ignore"):
+            terms = R.TABLE[f"{name}_logpdf"](x, *params)
+            exp = float(np.sum(terms))
+        rc, got = _host_sum_acc(hostlib, name, x, params)
+        assert rc == 0
+        if math.isfinite(exp):
+            fin = terms[np.isfinite(terms)]
+            assert abs(got - math.fsum(terms)) <= 1e-12 * float(np.sum(np.abs(fin))), (name, extra, got, exp)
+        else:
+            assert (math.isnan(exp) and math.isnan(got)) or got == exp, (name, extra, got, exp)
+    # a == 1 (coefficient zero): x = 0 contributes xlogy0 = 0, not 0 * -inf
+    x = np.concatenate([rng.gamma(1.0, 1.0, 100), [0.0]])
+    rc, got = _host_sum_acc(hostlib, "gamma", x, (1.0, 2.0))
+    assert rc == 0 and abs(got - math.fsum(R.gamma_logpdf(x, 1.0, 2.0))) <= 1e-12 * 200
+    # coefficients above the limit decline (the kernel then sums logpdf() itself)
+    assert _host_sum_acc(hostlib, "gamma", x, (5000.0, 2.0))[0] == 1
+    assert _host_sum_acc(hostlib, "beta", x, (2.0, 5000.0))[0] == 1
+    assert _host_sum_acc(hostlib, "studentt", x, (2e5, 0.0, 1.0))[0] == 1
