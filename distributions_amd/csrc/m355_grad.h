@@ -213,6 +213,27 @@ template <> struct Grad<M355_GAMMA> {  // gamma.py:77-82 (quirk Q2: xlogy0)
   template <class X, class K> static M355_DEV auto lp(X x, const K& k) {
     return outside(val(x) < 0.0, (dxlogy0(k.a, x) - k.b * x) + k.c);
   }
+  // x as data, scalar parameters: sum_i lp(x_i) = a * sum log x_i - b * sum x_i + n * c is linear in the
+  // sufficient statistics, so the dual-number expression is evaluated once per thread on the statistics
+  // (sum of logarithms as a LogProd, m355_math.h) instead of once per element.  Elements outside
+  // [min normal, inf) go through lp() itself (stats_add returns false).
+  struct Stats {
+    LogProd px;
+    double sx = 0.0;
+    int cnt = 0;
+  };
+  static M355_DEV bool stats_ok(const double* p) { return __builtin_fabs(p[0] - 1.0) <= kSumAccMaxCoef; }
+  template <class K> static M355_DEV bool stats_add(Stats& s, double x, const K&) {
+    if (!((x >= kMinNormal) & (x < kInf))) return false;
+    s.px.mul(x);
+    s.sx += x;
+    ++s.cnt;
+    return true;
+  }
+  static M355_DEV void stats_renorm(Stats& s) { s.px.renorm(); }
+  template <class K> static M355_DEV auto stats_lp(const Stats& s, const K& k) {
+    return (k.a * s.px.log() - k.b * s.sx) + k.c * (double)s.cnt;
+  }
 };
 
 template <> struct Grad<M355_BETA> {  // beta.py:102-108
@@ -220,6 +241,28 @@ template <> struct Grad<M355_BETA> {  // beta.py:102-108
   template <class A, class B> static M355_DEV auto pre(A a, B b) { return pack(a - 1.0, b - 1.0, dbetaln(a, b)); }
   template <class X, class K> static M355_DEV auto lp(X x, const K& k) {
     return outside((val(x) < 0.0) || (val(x) > 1.0), (dxlogy0(k.a, x) + dxlogy0(k.b, 1.0 - x)) - k.c);
+  }
+  // sufficient statistics sum log x, sum log(1 - x) (see Grad<M355_GAMMA>::Stats)
+  struct Stats {
+    LogProd px, pc;
+    int cnt = 0;
+  };
+  static M355_DEV bool stats_ok(const double* p) {
+    return (__builtin_fabs(p[0] - 1.0) <= kSumAccMaxCoef) & (__builtin_fabs(p[1] - 1.0) <= kSumAccMaxCoef);
+  }
+  template <class K> static M355_DEV bool stats_add(Stats& s, double x, const K&) {
+    if (!((x >= kMinNormal) & (x < 1.0))) return false;
+    s.px.mul(x);
+    s.pc.mul(1.0 - x);
+    ++s.cnt;
+    return true;
+  }
+  static M355_DEV void stats_renorm(Stats& s) {
+    s.px.renorm();
+    s.pc.renorm();
+  }
+  template <class K> static M355_DEV auto stats_lp(const Stats& s, const K& k) {
+    return (k.a * s.px.log() + k.b * s.pc.log()) - k.c * (double)s.cnt;
   }
 };
 
@@ -232,6 +275,35 @@ template <> struct Grad<M355_STUDENTT> {  // studentt.py:108-119 (quirk Q1: the 
   template <class X, class K> static M355_DEV auto lp(X x, const K& k) {
     if (val(k.a) > 1e5) return widen<0xFu>(dnormal_logcdf_z((x - k.b) * k.c));
     return widen<0xFu>(k.d - k.e * dlog1p(dsqr(x - k.b) * k.f));
+  }
+  // x as data, scalar parameters: sum_i lp = n d - e T with T = sum log1p(w_i), w = (x - mu)^2 f.  T's value is a
+  // LogProd (+ the first-order rounding of 1 + w, as flog1p_tab); its partials are dT/dmu = -2 f sum delta/(1+w)
+  // and dT/df = sum delta^2/(1+w): one division per element instead of a logarithm and a division.
+  struct Stats {
+    LogProd pu;
+    double corr = 0.0, s1 = 0.0, s2 = 0.0;
+    int cnt = 0;
+  };
+  static M355_DEV bool stats_ok(const double* p) { return (0.5 * (p[0] + 1.0) <= kSumAccMaxCoef) & !(p[0] > 1e5); }
+  template <class K> static M355_DEV bool stats_add(Stats& s, double x, const K& k) {
+    const double d = x - val(k.b);
+    const double w = d * d * val(k.f);
+    if (!(w < 0x1p1000)) return false;
+    const double u = 1.0 + w;
+    const double c = w - (u - 1.0);
+    s.corr += (w < 0.5) ? c * (2.0 - u) : 0.0;
+    s.pu.mul(u);
+    const double r = 1.0 / u;
+    const double dr = d * r;
+    s.s1 += dr;
+    s.s2 += d * dr;
+    ++s.cnt;
+    return true;
+  }
+  static M355_DEV void stats_renorm(Stats& s) { s.pu.renorm(); }
+  template <class K> static M355_DEV auto stats_lp(const Stats& s, const K& k) {
+    const auto t = comb(s.pu.log() + s.corr, -2.0 * val(k.f) * s.s1, k.b, s.s2, k.f);
+    return widen<0xEu>(k.d * (double)s.cnt - k.e * t);
   }
 };
 

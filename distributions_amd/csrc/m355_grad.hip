@@ -44,6 +44,11 @@ template <int S> M355_DEV void block_reduce_multi(double (&acc)[S], double* __re
   }
 }
 
+// Grad<D>::Stats: with x as data and scalar parameters the sum of the graph over a thread's elements is a
+// function of a few sufficient statistics (m355_grad.h)
+template <class T, class = void> struct has_grad_stats : std::false_type {};
+template <class T> struct has_grad_stats<T, std::void_t<typename T::Stats>> : std::true_type {};
+
 template <int D, bool WRITE_DX>
 __global__ __launch_bounds__(kBlock) void k_grad_scalar(const void* __restrict__ x, int xdt, void* __restrict__ dx,
                                                         int odt, long long n, const ParamVals pv,
@@ -56,6 +61,45 @@ __global__ __launch_bounds__(kBlock) void k_grad_scalar(const void* __restrict__
 #pragma unroll
   for (int s = 0; s < S; ++s) acc[s] = 0.0;
   const long long ntiles = n / kTile;
+  if constexpr (!WRITE_DX && has_grad_stats<G>::value) {
+    if (G::stats_ok(pv.p)) {  // uniform: parameters are kernel arguments
+      typename G::Stats st;
+      int since = 0;
+      auto add = [&](double xv) {
+        if (!G::stats_add(st, xv, k)) {  // zero, subnormal, out of support, inf, NaN: the graph itself
+          double r[S];
+          grad_eval<G, 0u>(xv, k, r);
+#pragma unroll
+          for (int s = 0; s < S; ++s) acc[s] += r[s];
+        }
+      };
+      for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const long long base = tile * kTile + threadIdx.x * kVec;
+        double v[kUnroll][kVec];
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) load2<false>(x, xdt, base + u * (kBlock * kVec), v[u][0], v[u][1]);
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) {
+          add(v[u][0]);
+          add(v[u][1]);
+        }
+        if (++since == kRenormEvery) {
+          since = 0;
+          G::stats_renorm(st);
+        }
+      }
+      for (long long i = ntiles * kTile + (long long)blockIdx.x * kBlock + threadIdx.x; i < n;
+           i += (long long)gridDim.x * kBlock)
+        add(load1(x, xdt, i));
+      double r[S];
+      grad_unpack(G::stats_lp(st, k), r, std::make_integer_sequence<int, 1 + G::NP>{});
+#pragma unroll
+      for (int s = 0; s < S; ++s) acc[s] += r[s];
+      acc[1] = kNaN;
+      block_reduce_multi<S>(acc, partials, gridDim.x);
+      return;
+    }
+  }
   for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const long long base = tile * kTile + threadIdx.x * kVec;
     double v[kUnroll][kVec];

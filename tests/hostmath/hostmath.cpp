@@ -126,4 +126,35 @@ extern "C" int hm_grad(int dist, long n, const double* x, const double* p, doubl
   }
   return -1;
 }
+// Grad<D>::Stats (value and parameter gradients of the summed logpdf from sufficient statistics), one "thread"
+// over all n elements; out[0] = sum logpdf, out[2 + j] = sum d/dparam_j (out[1], d/dx, is not on this path).
+template <int D> static int run_grad_stats(long n, const double* x, const double* p, double* out) {
+  using G = Grad<D>;
+  constexpr int S = 2 + G::NP;
+  if (!G::stats_ok(p)) return 1;
+  const auto k = grad_pre<G>(p);
+  typename G::Stats st;
+  for (int s = 0; s < S; ++s) out[s] = 0.0;
+  for (long i = 0; i < n; ++i) {
+    if (!G::stats_add(st, x[i], k)) {
+      double r[S];
+      grad_eval<G, 0u>(x[i], k, r);
+      for (int s = 0; s < S; ++s) out[s] += r[s];
+    }
+    if ((i & 255) == 255) G::stats_renorm(st);
+  }
+  double r[S];
+  grad_unpack(G::stats_lp(st, k), r, std::make_integer_sequence<int, 1 + G::NP>{});
+  for (int s = 0; s < S; ++s) out[s] += r[s];
+  return 0;
+}
+extern "C" int hm_grad_stats(int dist, long n, const double* x, const double* p, double* out) {
+  switch (dist) {
+    case M355_GAMMA: return run_grad_stats<M355_GAMMA>(n, x, p, out);
+    case M355_BETA: return run_grad_stats<M355_BETA>(n, x, p, out);
+    case M355_STUDENTT: return run_grad_stats<M355_STUDENTT>(n, x, p, out);
+  }
+  return -1;
+}
+
 extern "C" void hm_digamma(long n, const double* x, double* out) { for (long i = 0; i < n; ++i) out[i] = digamma_(x[i]); }

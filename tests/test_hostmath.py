@@ -388,3 +388,32 @@ def test_host_sum_acc_exceptional_elements(hostlib):
     assert _host_sum_acc(hostlib, "gamma", x, (5000.0, 2.0))[0] == 1
     assert _host_sum_acc(hostlib, "beta", x, (2.0, 5000.0))[0] == 1
     assert _host_sum_acc(hostlib, "studentt", x, (2e5, 0.0, 1.0))[0] == 1
+
+
+@pytest.mark.parametrize("name, params, draw", _SUM_ACC_CASES, ids=[f"{c[0]}-{c[1]}" for c in _SUM_ACC_CASES])
+def test_host_grad_stats_vs_oracle(hostlib, name, params, draw):
+    """Grad<>::Stats (csrc/m355_grad.h: value and parameter gradients of the summed logpdf from sufficient
+    statistics) against the sums of the oracle's per-element value and partials: 1e-12 * sum |term| per slot."""
+    import math
+
+    from oracle import restatement_grad as G
+
+    rng = np.random.default_rng(79)
+    for n in (1, 9, 50_001):
+        x = draw(rng, n)
+        val, grads = G.logpdf_grad(name, x, *params)
+        out = np.empty(2 + len(params))
+        p = np.ascontiguousarray(np.asarray(list(params) + [0.0] * 4, dtype=np.float64)[:4])
+        assert hostlib.hm_grad_stats(DIST[name], ctypes.c_long(x.size), _ptr(np.ascontiguousarray(x)), _ptr(p), _ptr(out)) == 0
+        for got, terms in zip([out[0]] + list(out[2:]), [val] + list(grads[1:])):
+            terms = np.broadcast_to(terms, x.shape)
+            assert abs(got - math.fsum(terms)) <= 1e-12 * max(float(np.sum(np.abs(terms))), 1.0), (name, params, n, got, math.fsum(terms))
+    # exceptional elements take the graph itself: -inf value, partials as the elementwise path gives them
+    x = np.concatenate([draw(rng, 100), [-1.0] if name != "studentt" else [np.inf]])
+    with np.errstate(all="ignore"):
+        val, grads = G.logpdf_grad(name, x, *params)
+    out = np.empty(2 + len(params))
+    assert hostlib.hm_grad_stats(DIST[name], ctypes.c_long(x.size), _ptr(np.ascontiguousarray(x)), _ptr(p), _ptr(out)) == 0
+    with np.errstate(all="ignore"):
+        exp0 = float(np.sum(val))
+    assert out[0] == exp0 or (math.isnan(out[0]) and math.isnan(exp0))
