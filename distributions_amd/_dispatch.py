@@ -13,7 +13,7 @@ from typing import Any, List, Optional, Sequence, Tuple
 import numpy as np
 
 from . import _lib
-from ._lib import DIST, F32, F64, FN, I64, NPARAMS, Operand
+from ._lib import DIST, F32, F64, FN, I64, NPARAMS, STAT, Operand
 
 
 # ------------------------------------------------------------------------------------------ plan
@@ -281,6 +281,36 @@ def logpdf_grad(dist: str, x: Any, *params: Any, elementwise: bool = False, x_gr
         return sums[0].reshape(()), grads
     host = sums.cpu().numpy()
     return float(host[0]), [g.cpu().numpy() if g is not None else None for g in grads]
+
+
+# --------------------------------------------------------------------------------------- moments
+def moment(dist: str, stat: str, *params: Any):
+    """<dist>.<stat>(*params) for stat in mean / mode / median / var / std / skewness / kurtosis / entropy
+    (m355_moment): one value per parameter set of the broadcast shape of the parameters.  float64, or float32
+    when every floating array parameter is float32; torch tensor out if any parameter is a torch tensor."""
+    if len(params) != NPARAMS[dist]:
+        raise TypeError(f"{dist}.{stat} takes {NPARAMS[dist]} parameters, got {len(params)}")
+    torch = _torch()
+    L = _lib.lib()
+    pl = plan(0.0, params)
+    device = _device_of(params, torch)
+    out_dt = torch.float32 if pl.out_f32 else torch.float64
+    with torch.cuda.device(device):
+        out = torch.empty(pl.n, dtype=out_dt, device=device)
+        if pl.n:
+            ops, keep = _build_operands(pl, (0.0, *params), torch, device)
+            stream = torch.cuda.current_stream(device).cuda_stream
+            rc = L.m355_moment(DIST[dist], STAT[stat], F32 if pl.out_f32 else F64, pl.n, len(params),
+                               ctypes.cast(ctypes.byref(ops, ctypes.sizeof(Operand)), ctypes.POINTER(Operand)),
+                               out.data_ptr(), stream)
+            _lib.check(rc)
+            del keep
+    out = out.reshape(pl.shape)
+    if dist == "discreteweibull" and stat == "mode":  # pt.cast(..., "int64"), discreteweibull.py:19
+        out = out.to(torch.int64)
+    if _wants_torch(params):
+        return out
+    return out.cpu().numpy()
 
 
 # ------------------------------------------------------------------------------------------- rvs

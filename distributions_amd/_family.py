@@ -6,9 +6,10 @@ from __future__ import annotations
 
 from ._dispatch import elemwise as _elemwise
 from ._dispatch import logpdf_grad as _logpdf_grad
+from ._dispatch import moment as _moment
 from ._dispatch import rvs as _rvs
 from ._dispatch import sumlogp as _sumlogp
-from ._lib import FN, GRAD, PARAMS
+from ._lib import FN, GRAD, PARAMS, STAT
 
 
 def export(ns: dict, dist: str, cites: dict | None = None) -> None:
@@ -39,8 +40,22 @@ def export(ns: dict, dist: str, cites: dict | None = None) -> None:
     loc["rvs"].__doc__ = (f"{dist}.py:{cites.get('rvs', '?')} of the reference; Philox counter-based draws, statistically "
                           "equivalent to the reference sampler (SURVEY.md quirk Q3).")
     ns["rvs"] = loc["rvs"]
+    export_moments(ns, dist)
     if dist in GRAD:
         export_grad(ns, dist)
+
+
+def export_moments(ns: dict, dist: str) -> None:
+    """mean / mode / median / var / std / skewness / kurtosis / entropy of `dist` with the reference's signature
+    (the parameters only), evaluated per parameter set by m355_moment (csrc/m355_moments.h)."""
+    sig = ", ".join(PARAMS[dist])
+    for st in STAT:
+        loc: dict = {}
+        exec(f"def {st}({sig}):\n    return _moment({dist!r}, {st!r}, {sig})\n", {"_moment": _moment}, loc)  # noqa: S102
+        f = loc[st]
+        f.__doc__ = f"{dist}.{st} of the reference ({dist}.py, moment block), one value per parameter set."
+        f.__module__ = ns.get("__name__", __name__)
+        ns[st] = f
 
 
 def export_grad(ns: dict, dist: str) -> None:

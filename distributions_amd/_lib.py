@@ -69,6 +69,8 @@ DISCRETE = ("poisson", "binomial", "bernoulli", "geometric", "discreteuniform", 
 # distributions with a gradient kernel (m355_grad_supported): the continuous families, poisson and binomial
 GRAD = tuple(n for n in list(PARAMS)[:28] if n not in DISCRETE) + ("poisson", "binomial")
 FN = {"logpdf": 0, "logcdf": 1, "logsf": 2, "ppf": 3, "pdf": 4, "cdf": 5, "sf": 6, "isf": 7}
+# enum m355_stat of include/m355_dist.h: the moment functions every module of the reference defines
+STAT = {"mean": 0, "mode": 1, "median": 2, "var": 3, "std": 4, "skewness": 5, "kurtosis": 6, "entropy": 7}
 
 
 class Operand(ctypes.Structure):
@@ -114,6 +116,8 @@ def lib():
     L.m355_rvs.restype = i32
     L.m355_rvs.argtypes = [i32, i32, i64, i32, op, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint64, vp, vp]
     L.m355_grad_supported.restype = i32
+    L.m355_moment.restype = i32
+    L.m355_moment.argtypes = [i32, i32, i32, i64, i32, op, vp, vp]
     L.m355_grad_supported.argtypes = [i32]
     L.m355_logpdf_grad.restype = i32
     L.m355_logpdf_grad.argtypes = [i32, i32, i64, op, i32, op, vp, vp, ctypes.POINTER(vp), vp, sz, vp]

@@ -225,4 +225,35 @@ int m355_rvs(int dist, int out_dtype, int64_t n, int nparams, const m355_operand
                                     static_cast<hipStream_t>(stream)));
 }
 
+int m355_moment(int dist, int stat, int out_dtype, int64_t n, int nparams, const m355_operand* params, void* out,
+                void* stream) {
+  const int np = nparams_of(dist);
+  if (np < 0) return fail(M355_ERR_INVALID, "unknown distribution id %d", dist);
+  if (stat < 0 || stat >= M355_STAT_COUNT) return fail(M355_ERR_INVALID, "unknown moment function id %d", stat);
+  if (nparams != np) return fail(M355_ERR_INVALID, "distribution %d takes %d parameters, got %d", dist, np, nparams);
+  if (n < 0) return fail(M355_ERR_INVALID, "n must be >= 0");
+  if (params == nullptr) return fail(M355_ERR_INVALID, "params must not be NULL");
+  if (out_dtype != M355_F64 && out_dtype != M355_F32) return fail(M355_ERR_INVALID, "out_dtype %d not valid for a moment", out_dtype);
+  if (n == 0) return M355_OK;
+  if (out == nullptr) return fail(M355_ERR_INVALID, "out must not be NULL");
+  m355::MomentArgs a;
+  a.stat = stat;
+  a.out_dtype = out_dtype;
+  a.n = n;
+  a.out = out;
+  a.stream = static_cast<hipStream_t>(stream);
+  a.ops.x = m355::DevOperand{nullptr, 0.0, 1, 1, M355_F64};
+  for (int q = 0; q < m355::kMaxParams; ++q) {
+    a.ops.p[q] = m355::DevOperand{nullptr, 0.0, 1, 1, M355_F64};
+    if (q < np && !convert(params[q], n, true, a.ops.p[q], "parameter")) return M355_ERR_INVALID;
+  }
+  switch (dist) {
+#define M355_MOMENT_CASE(ID, name, np_) \
+  case ID: return check_launch(m355_launch_moment_##name(a));
+    M355_DIST_LIST(M355_MOMENT_CASE)
+#undef M355_MOMENT_CASE
+  }
+  return fail(M355_ERR_INVALID, "unknown distribution id %d", dist);
+}
+
 }  // extern "C"

@@ -25,6 +25,7 @@
 #include <type_traits>
 
 #include "m355_dists4.h"
+#include "m355_moments.h"
 
 namespace m355 {
 
@@ -570,13 +571,69 @@ template <int D, bool REDUCE> int launch_dist(const LaunchArgs& a) {
   return -1000;  // unsupported (dist, fn)
 }
 
+// ------------------------------------------------------------------------------------- moments
+// out[i] = Mom<D>::eval(stat, params_i) (m355_moments.h).  k_moment_thread: one thread per parameter set (closed
+// forms, medians through ppf).  k_moment_wave: one wavefront per parameter set for the stats in Mom<D>::kWave --
+// the lanes share the parameter set, split the quadrature / support sums and combine them with xor-shuffles, so
+// the 4 x 1000 integrand evaluations of e.g. rice.kurtosis take ~63 evaluations per lane.
+struct MomentArgs {
+  int stat;
+  int out_dtype;
+  long long n;
+  GenericOps ops;  // ops.x unused
+  void* out;
+  hipStream_t stream;
+};
+
+template <int D>
+__global__ __launch_bounds__(kBlock) void k_moment_thread(GenericOps ops, int stat, void* __restrict__ out, int odt, long long n) {
+  const bool small = n <= 0xffffffffll;
+  for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < n; i += (long long)gridDim.x * kBlock) {
+    double pp[kMaxParams] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int q = 0; q < Dist<D>::NP; ++q) pp[q] = fetch_operand(ops.p[q], (unsigned long long)i, small);
+    store1(out, odt, i, Mom<D>::template eval<SerialCtx>(stat, pp));
+  }
+}
+
+template <int D>
+__global__ __launch_bounds__(kBlock) void k_moment_wave(GenericOps ops, int stat, void* __restrict__ out, int odt, long long n) {
+  const bool small = n <= 0xffffffffll;
+  const long long wave = ((long long)blockIdx.x * kBlock + threadIdx.x) >> 6, nwaves = ((long long)gridDim.x * kBlock) >> 6;
+  for (long long i = wave; i < n; i += nwaves) {  // uniform per wavefront: every lane reaches the shuffles
+    double pp[kMaxParams] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int q = 0; q < Dist<D>::NP; ++q) pp[q] = fetch_operand(ops.p[q], (unsigned long long)i, small);
+    const double r = Mom<D>::template eval<WaveCtx>(stat, pp);
+    if ((threadIdx.x & 63) == 0) store1(out, odt, i, r);
+  }
+}
+
+template <int D> int launch_moment(const MomentArgs& a) {
+  if (a.stat < 0 || a.stat >= M355_STAT_COUNT) return -1000;
+  if ((Mom<D>::kWave >> a.stat) & 1u) {
+    const long long want = (a.n + (kBlock / 64) - 1) / (kBlock / 64);
+    const int blocks = (int)(want < 1 ? 1 : (want > kMaxBlocks ? kMaxBlocks : want));
+    hipLaunchKernelGGL((k_moment_wave<D>), dim3(blocks), dim3(kBlock), 0, a.stream, a.ops, a.stat, a.out, a.out_dtype, a.n);
+  } else {
+    const long long want = (a.n + kBlock - 1) / kBlock;
+    const int blocks = (int)(want < 1 ? 1 : (want > kMaxBlocks ? kMaxBlocks : want));
+    hipLaunchKernelGGL((k_moment_thread<D>), dim3(blocks), dim3(kBlock), 0, a.stream, a.ops, a.stat, a.out, a.out_dtype, a.n);
+  }
+  return (int)hipGetLastError();
+}
+
 }  // namespace m355
 
 // One translation unit per distribution defines its launcher (keeps hipcc compile times parallel).
 #define M355_DECLARE_LAUNCH(ID, name, np) int m355_launch_##name(const m355::LaunchArgs& a);
 M355_DIST_LIST(M355_DECLARE_LAUNCH)
 #undef M355_DECLARE_LAUNCH
+#define M355_DECLARE_MOMENT(ID, name, np) int m355_launch_moment_##name(const m355::MomentArgs& a);
+M355_DIST_LIST(M355_DECLARE_MOMENT)
+#undef M355_DECLARE_MOMENT
 #define M355_DEFINE_LAUNCH(ID, name)                                                                  \
   int m355_launch_##name(const m355::LaunchArgs& a) {                                                  \
     return a.partials ? m355::launch_dist<ID, true>(a) : m355::launch_dist<ID, false>(a);              \
-  }
+  }                                                                                                    \
+  int m355_launch_moment_##name(const m355::MomentArgs& a) { return m355::launch_moment<ID>(a); }

@@ -60,3 +60,7 @@ def rvs(nu, mu, sigma, size=None, random_state=None):
 from ._family import export_grad as _export_grad  # noqa: E402
 
 _export_grad(globals(), "studentt")
+
+from ._family import export_moments as _export_moments  # noqa: E402
+
+_export_moments(globals(), "studentt")

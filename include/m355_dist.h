@@ -189,6 +189,31 @@ int m355_rvs(int dist, int out_dtype, int64_t n, int nparams, const m355_operand
              uint32_t stream_id, uint64_t counter_offset, void* out, void* stream);
 
 /*
+ * Moment functions of a distribution, one value per parameter set: out[i] = <dist>.<stat>(*params_i), i in [0, n).
+ * Replaces the module-level mean / mode / median / var / std / skewness / kurtosis / entropy of every module of
+ * the reference (normal.py:6-43, gamma.py:8-37, beta.py:9-63, ... one block per module) and the helpers they
+ * call: continuous_entropy / discrete_entropy / discrete_moment / continuous_moment (+ _skewness, _kurtosis),
+ * continuous_mode and zi_mode (helper.py:99-322, 375-446), the Gauss-Hermite sums of logitnormal.py:12-92.
+ * Parameters as in m355_elemwise (float64 arrays or scalars, indexed by (i / div) % mod); the helpers that take
+ * arange(min, max) or linspace(min, max) of the parameters are evaluated per parameter set.  out_dtype:
+ * M355_F64 / M355_F32.  Closed forms run one thread per parameter set; the stats that sum over many points
+ * (1000-point trapezoids, sums over a discrete support) run one 64-lane wavefront per parameter set.
+ */
+enum m355_stat {
+  M355_MEAN = 0,
+  M355_MODE = 1,
+  M355_MEDIAN = 2,
+  M355_VAR = 3,
+  M355_STD = 4,
+  M355_SKEWNESS = 5,
+  M355_KURTOSIS = 6,
+  M355_ENTROPY = 7,
+  M355_STAT_COUNT = 8
+};
+int m355_moment(int dist, int stat, int out_dtype, int64_t n, int nparams, const m355_operand* params, void* out,
+                void* stream);
+
+/*
  * Multivariate normal / Student t log-density: out[r] = logpdf(x[r, :]) for r in [0, n), x row-major
  * n x d (d <= 128).  Replaces mvnormal.logpdf (mvnormal.py:80-83 with quaddist_chol :17-37 and
  * _logdet_from_cholesky :9-14) for kind 0 and mvstudentt.logpdf (mvstudentt.py:58-68) for kind 1:

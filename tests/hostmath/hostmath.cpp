@@ -5,6 +5,7 @@
 #include "../../distributions_amd/csrc/m355_dist_list.h"
 #include "../../distributions_amd/csrc/m355_dists4.h"
 #include "../../distributions_amd/csrc/m355_grad.h"
+#include "../../distributions_amd/csrc/m355_moments.h"
 
 using namespace m355;
 
@@ -153,6 +154,19 @@ extern "C" int hm_grad_stats(int dist, long n, const double* x, const double* p,
     case M355_GAMMA: return run_grad_stats<M355_GAMMA>(n, x, p, out);
     case M355_BETA: return run_grad_stats<M355_BETA>(n, x, p, out);
     case M355_STUDENTT: return run_grad_stats<M355_STUDENTT>(n, x, p, out);
+  }
+  return -1;
+}
+
+// Mom<D>::eval<SerialCtx>(stat, p) for n parameter sets (p: n x 4, row-major)
+extern "C" int hm_moment(int dist, int stat, long n, const double* p, double* out) {
+  switch (dist) {
+#define HM_MOM(ID, name, np) \
+  case ID:                   \
+    for (long i = 0; i < n; ++i) out[i] = Mom<ID>::eval<SerialCtx>(stat, p + 4 * i); \
+    return 0;
+    M355_DIST_LIST(HM_MOM)
+#undef HM_MOM
   }
   return -1;
 }

@@ -27,7 +27,7 @@ _dp = ctypes.POINTER(ctypes.c_double)
 def hostlib():
     csrc = os.path.join(HERE, "..", "distributions_amd", "csrc")
     deps = [SRC] + [os.path.join(csrc, f) for f in ("m355_math.h", "m355_special.h", "m355_dists.h", "m355_dists2.h", "m355_dists3.h", "m355_dists4.h", "m355_grad.h",
-                                                    "m355_dist_list.h", "m355_rng.h")]
+                                                    "m355_dist_list.h", "m355_rng.h", "m355_moments.h", "m355_hermgauss70.h")]
     if not os.path.exists(LIB) or any(os.path.getmtime(d) > os.path.getmtime(LIB) for d in deps):
         subprocess.check_call(["g++", "-O2", "-mfma", "-std=c++17", "-shared", "-fPIC", "-o", LIB, SRC])
     return ctypes.CDLL(LIB)
@@ -417,3 +417,37 @@ def test_host_grad_stats_vs_oracle(hostlib, name, params, draw):
     with np.errstate(all="ignore"):
         exp0 = float(np.sum(val))
     assert out[0] == exp0 or (math.isnan(out[0]) and math.isnan(exp0))
+
+
+def host_moment(lib, name, stat, params):
+    from distributions_amd._lib import STAT
+
+    p = np.zeros((1, 4))
+    p[0, : len(params)] = params
+    out = np.empty(1)
+    assert lib.hm_moment(DIST[name], STAT[stat], ctypes.c_long(1), _ptr(p), _ptr(out)) == 0
+    return float(out[0])
+
+
+_MOMENT_CASES = H.grids() + H.moment_extra_cases()
+# stats whose device body calls erfinv / erfcinv (device libm only; the host stand-in returns NaN): GPU-tested
+_HOST_SKIP = {("normal", "median"), ("lognormal", "median"), ("halfnormal", "median"), ("logitnormal", "median"),
+              ("truncatednormal", "median"), ("exgaussian", "mode"), ("polyagamma", "median"), ("moyal", "median"),
+              ("skewnormal", "median")}
+
+
+@pytest.mark.parametrize("name, sp_dist, params, sp_params, support, kw", _MOMENT_CASES,
+                         ids=[f"{g[0]}-{'-'.join(str(v) for v in g[2])}" for g in _MOMENT_CASES])
+def test_host_moments_vs_oracle(hostlib, name, sp_dist, params, sp_params, support, kw):
+    """Mom<D>::eval (csrc/m355_moments.h, serial context) against oracle/restatement_moments.py at 1e-12 on every
+    parameter point of the reference's tests (medians through ppf at the ppf tolerances of tests/harness.py)."""
+    from oracle import restatement_moments as M
+
+    for stat in M.STATS:
+        if (name, stat) in _HOST_SKIP:
+            continue
+        if name in ("rice", "polyagamma") and stat in ("skewness", "kurtosis", "entropy", "mode", "median"):
+            continue  # 3 x 1000 Bessel / series evaluations per value in a Python-driven host loop: GPU-tested
+        exp = float(M.moment(name, stat, *params))
+        got = host_moment(hostlib, name, stat, params)
+        assert H.moment_close(name, stat, got, exp, params), (name, stat, params, got, exp)
