@@ -200,6 +200,34 @@ def config8(torch, n):
         del x, q, out
 
 
+def config9(torch, n):
+    """Moment functions over a batch of parameter sets (m355_moment): closed forms (thread per set), medians through
+    ppf, and the quadrature / support-sum stats (wavefront per set; `evals` = integrand evaluations, 1000 per
+    trapezoid, helper.py:99-322)."""
+    from distributions_amd import _dispatch
+
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev).manual_seed(11)
+
+    def u(lo, hi, m):
+        return lo + (hi - lo) * torch.rand(m, dtype=torch.float64, device=dev, generator=g)
+
+    cases = [("gamma", "entropy", n, lambda m: (u(0.5, 50, m), u(0.2, 5, m)), 1),
+             ("gamma", "median", n // 10, lambda m: (u(0.5, 50, m), u(0.2, 5, m)), 1),
+             ("weibull", "kurtosis", n, lambda m: (u(0.7, 9, m), u(0.5, 3, m)), 1),
+             ("logitnormal", "kurtosis", n // 10, lambda m: (u(-2, 2, m), u(0.2, 2, m)), 3 * 70),
+             ("binomial", "entropy", n // 10, lambda m: (torch.floor(u(5, 400, m)), u(0.05, 0.95, m)), 200),
+             ("skew_studentt", "entropy", n // 100, lambda m: (u(2, 9, m), u(2, 9, m), u(-1, 1, m), u(0.5, 2, m)), 1000),
+             ("rice", "kurtosis", n // 100, lambda m: (u(0.1, 6, m), u(0.5, 2, m)), 3000),
+             ("polyagamma", "entropy", n // 1000, lambda m: (u(0.5, 4, m), u(-2, 2, m)), 1000)]
+    for name, stat, m, make, evals in cases:
+        m = max(64, m)
+        params = make(m)
+        ms = timed(torch, lambda: _dispatch.moment(name, stat, *params), reps=3, warmup=1)
+        print(json.dumps({"config": 9, "dist": name, "stat": stat, "parameter_sets": m, "ms": round(ms, 4),
+                          "sets_per_s": float(f"{m / (ms * 1e-3):.4g}"), "integrand_evals_per_s": float(f"{m * evals / (ms * 1e-3):.4g}")}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--config", default="all")
@@ -220,6 +248,8 @@ def main():
         config7(torch, args.n or 100_000_000)
     if args.config in ("8", "all"):
         config8(torch, args.n or 10_000_000)
+    if args.config in ("9", "all"):
+        config9(torch, args.n or 10_000_000)
 
 
 if __name__ == "__main__":

@@ -42,6 +42,23 @@ def test_moments_vs_oracle(gpu, name, sp_dist, params, sp_params, support, kw):
         assert H.moment_close(name, stat, float(got), exp, params), (name, stat, params, float(got), exp)
 
 
+def test_moments_golden_vectors(gpu):
+    """The committed vectors (tests/golden/moments.json, made by tests/golden/make_golden_moments.py)."""
+    import json
+    import os
+
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "moments.json")) as f:
+        cases = json.load(f)
+    assert len(cases) > 250
+    for c in cases:
+        params = [float.fromhex(v) for v in c["params"]]
+        m = mod(c["dist"])
+        for stat, hx in c["values"].items():
+            exp = float.fromhex(hx)
+            got = float(getattr(m, stat)(*params))
+            assert H.moment_close(c["dist"], stat, got, exp, params), (c["dist"], stat, params, got, exp)
+
+
 def test_moments_reference_bar_vs_scipy(gpu):
     """tests/helper_scipy.py:45-48,163-238 of the reference on the HIP path: scipy.stats at rtol 1e-6 (entropy 1e-4)
     for the families with the default settings."""

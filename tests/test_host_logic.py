@@ -104,3 +104,5 @@ def test_every_module_imports_with_the_reference_signatures():
             assert len(set(sig)) == len(sig)
         assert list(inspect.signature(m.rvs).parameters) == list(names) + ["size", "random_state"]
         assert list(inspect.signature(m.sum_logpdf).parameters) == ["x"] + list(names)
+        for st in ("mean", "mode", "median", "var", "std", "skewness", "kurtosis", "entropy"):  # <dist>.py moment block
+            assert list(inspect.signature(getattr(m, st)).parameters) == list(names), (dist, st)
