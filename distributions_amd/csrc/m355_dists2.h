@@ -108,6 +108,25 @@ template <> struct Dist<M355_CAUCHY> {
   static M355_DEV double cdf(double x, const K& k) {  // cauchy.py:44-45
     return (1.0 / kPi) * atan_((x - k.alpha) / k.beta) + 0.5;
   }
+  // sum of logpdf with the logarithms carried as a product (m355_math.h LogProd; protocol of Dist<M355_GAMMA>::SumAcc)
+  struct SumAcc {
+    LogProd px;
+    double lin = 0.0, exc = 0.0;
+    int cnt = 0;
+  };
+  static M355_DEV void sum_renorm(SumAcc& s) { s.px.renorm(); }
+  static M355_DEV bool sum_ok(const K&) { return true; }
+  static M355_DEV void sum_add(SumAcc& s, double x, const K& k) {
+    const double z = (x - k.alpha) / k.beta;
+    const double u = 1.0 + z * z;
+    if (u < 0x1p1000) {
+      s.px.mul(u);
+      ++s.cnt;
+    } else {
+      s.exc += logpdf(x, k);
+    }
+  }
+  static M355_DEV double sum_finish(const SumAcc& s, const K& k) { return ((double)s.cnt * k.c - s.px.log()) + s.exc; }
   static M355_DEV double logpdf(double x, const K& k) {  // cauchy.py:72-73
     const double z = (x - k.alpha) / k.beta;
     return k.c - flog(1.0 + z * z);
@@ -138,6 +157,25 @@ template <> struct Dist<M355_HALFCAUCHY> {
   static M355_DEV double logcdf(double x, const K& k) {  // halfcauchy.py:42-47
     return (x < 0.0) ? -kInf : flog(2.0 * atan_(x / k.beta) / kPi);
   }
+  // sum of logpdf with the logarithms carried as a product (m355_math.h LogProd; protocol of Dist<M355_GAMMA>::SumAcc)
+  struct SumAcc {
+    LogProd px;
+    double lin = 0.0, exc = 0.0;
+    int cnt = 0;
+  };
+  static M355_DEV void sum_renorm(SumAcc& s) { s.px.renorm(); }
+  static M355_DEV bool sum_ok(const K&) { return true; }
+  static M355_DEV void sum_add(SumAcc& s, double x, const K& k) {
+    const double z = x / k.beta;
+    const double u = 1.0 + z * z;
+    if ((x >= 0.0) & (u < 0x1p1000)) {
+      s.px.mul(u);
+      ++s.cnt;
+    } else {
+      s.exc += logpdf(x, k);
+    }
+  }
+  static M355_DEV double sum_finish(const SumAcc& s, const K& k) { return ((double)s.cnt * k.c - s.px.log()) + s.exc; }
   static M355_DEV double logpdf(double x, const K& k) {  // halfcauchy.py:72-75
     const double z = x / k.beta;
     return (x < 0.0) ? -kInf : k.c - flog(1.0 + z * z);
@@ -279,6 +317,25 @@ template <> struct Dist<M355_PARETO> {
   static M355_HD K derive(const double* p) { return K{p[0], p[1], flog(p[0]) + p[0] * flog(p[1])}; }
   static M355_DEV double cdf(double x, const K& k) {  // pareto.py:47-48
     return (x < k.m) ? 0.0 : 1.0 - pow_(k.m / x, k.alpha);
+  }
+  // sum of logpdf with the logarithms carried as a product (m355_math.h LogProd; protocol of Dist<M355_GAMMA>::SumAcc)
+  struct SumAcc {
+    LogProd px;
+    double lin = 0.0, exc = 0.0;
+    int cnt = 0;
+  };
+  static M355_DEV void sum_renorm(SumAcc& s) { s.px.renorm(); }
+  static M355_DEV bool sum_ok(const K& k) { return __builtin_fabs(k.alpha + 1.0) <= kSumAccMaxCoef; }
+  static M355_DEV void sum_add(SumAcc& s, double x, const K& k) {
+    if ((x >= k.m) & (x >= kMinNormal) & (x < kInf)) {
+      s.px.mul(x);
+      ++s.cnt;
+    } else {
+      s.exc += eval<M355_LOGPDF>(x, k);
+    }
+  }
+  static M355_DEV double sum_finish(const SumAcc& s, const K& k) {
+    return ((double)s.cnt * k.c - (k.alpha + 1.0) * s.px.log()) + s.exc;
   }
   template <int FN> static M355_DEV double eval(double x, const K& k) {
     if constexpr (FN == M355_LOGPDF) return (x < k.m) ? -kInf : k.c - (k.alpha + 1.0) * flog(x);  // pareto.py:77-80
@@ -537,6 +594,26 @@ template <> struct Dist<M355_INVERSEGAMMA> {
     const double lga = lgamma_(p[0]);
     return K{p[0], p[1], lga, p[0] * flog(p[1]) - lga};
   }
+  // sum of logpdf with the logarithms carried as a product (m355_math.h LogProd; protocol of Dist<M355_GAMMA>::SumAcc)
+  struct SumAcc {
+    LogProd px;
+    double lin = 0.0, exc = 0.0;
+    int cnt = 0;
+  };
+  static M355_DEV void sum_renorm(SumAcc& s) { s.px.renorm(); }
+  static M355_DEV bool sum_ok(const K& k) { return __builtin_fabs(k.alpha + 1.0) <= kSumAccMaxCoef; }
+  static M355_DEV void sum_add(SumAcc& s, double x, const K& k) {
+    if ((x >= kMinNormal) & (x < kInf)) {
+      s.px.mul(x);
+      s.lin += k.beta / x;
+      ++s.cnt;
+    } else {
+      s.exc += logpdf(x, k);
+    }
+  }
+  static M355_DEV double sum_finish(const SumAcc& s, const K& k) {
+    return (((double)s.cnt * k.c - (k.alpha + 1.0) * s.px.log()) - s.lin) + s.exc;
+  }
   static M355_DEV double logpdf(double x, const K& k) {  // inversegamma.py:76-81
     return (x <= 0.0) ? -kInf : (k.c - (k.alpha + 1.0) * flog(x)) - k.beta / x;
   }
@@ -569,6 +646,26 @@ template <> struct Dist<M355_CHISQUARED> {
   }
   static M355_DEV double cdf(double x, const K& k) {  // chisquared.py:40-41
     return cdf_bounds(gammainc_p(k.h, x / 2.0, k.lgh), x, 0.0, kInf);
+  }
+  // sum of logpdf with the logarithms carried as a product (m355_math.h LogProd; protocol of Dist<M355_GAMMA>::SumAcc)
+  struct SumAcc {
+    LogProd px;
+    double lin = 0.0, exc = 0.0;
+    int cnt = 0;
+  };
+  static M355_DEV void sum_renorm(SumAcc& s) { s.px.renorm(); }
+  static M355_DEV bool sum_ok(const K& k) { return __builtin_fabs(k.h - 1.0) <= kSumAccMaxCoef; }
+  static M355_DEV void sum_add(SumAcc& s, double x, const K& k) {
+    if ((x >= kMinNormal) & (x < kInf)) {
+      s.px.mul(x);
+      s.lin += x;
+      ++s.cnt;
+    } else {
+      s.exc += eval<M355_LOGPDF>(x, k);
+    }
+  }
+  static M355_DEV double sum_finish(const SumAcc& s, const K& k) {
+    return (((k.h - 1.0) * s.px.log() - s.lin / 2.0) + (double)s.cnt * k.c) + s.exc;
   }
   template <int FN> static M355_DEV double eval(double x, const K& k) {
     if constexpr (FN == M355_LOGPDF)  // chisquared.py:69-74
@@ -603,6 +700,26 @@ template <> struct Dist<M355_SCALEDINVERSECHISQUARED> {
   }
   static M355_DEV double logsf(double x, const K& k) {  // scaledinversechisquared.py:88-90
     return (x <= 0.0) ? 0.0 : flog(gammainc_p(k.h, k.ht / x, k.lgh));
+  }
+  // sum of logpdf with the logarithms carried as a product (m355_math.h LogProd; protocol of Dist<M355_GAMMA>::SumAcc)
+  struct SumAcc {
+    LogProd px;
+    double lin = 0.0, exc = 0.0;
+    int cnt = 0;
+  };
+  static M355_DEV void sum_renorm(SumAcc& s) { s.px.renorm(); }
+  static M355_DEV bool sum_ok(const K& k) { return __builtin_fabs(k.h + 1.0) <= kSumAccMaxCoef; }
+  static M355_DEV void sum_add(SumAcc& s, double x, const K& k) {
+    if ((x >= kMinNormal) & (x < kInf)) {
+      s.px.mul(x);
+      s.lin += k.ht / x;
+      ++s.cnt;
+    } else {
+      s.exc += eval<M355_LOGPDF>(x, k);
+    }
+  }
+  static M355_DEV double sum_finish(const SumAcc& s, const K& k) {
+    return ((-(s.px.log() * (k.h + 1.0)) - s.lin) + (double)s.cnt * k.c) + s.exc;
   }
   template <int FN> static M355_DEV double eval(double x, const K& k) {
     if constexpr (FN == M355_LOGPDF)  // scaledinversechisquared.py:75-85
@@ -681,6 +798,32 @@ template <> struct Dist<M355_BETASCALED> {
     k.lbeta = lbeta_(p[0], p[1]);
     k.c = xlogy0_l(p[0] + p[1] - 1.0, flog(p[3] - p[2])) + k.lbeta;
     return k;
+  }
+  // sum of logpdf: sum log(x - lo), sum log(hi - x) as LogProds (protocol of Dist<M355_GAMMA>::SumAcc)
+  struct SumAcc {
+    LogProd px, pc;
+    double exc = 0.0;
+    int cnt = 0;
+  };
+  static M355_DEV void sum_renorm(SumAcc& s) {
+    s.px.renorm();
+    s.pc.renorm();
+  }
+  static M355_DEV bool sum_ok(const K& k) {
+    return (__builtin_fabs(k.a - 1.0) <= kSumAccMaxCoef) & (__builtin_fabs(k.b - 1.0) <= kSumAccMaxCoef);
+  }
+  static M355_DEV void sum_add(SumAcc& s, double x, const K& k) {
+    const double l = x - k.lo, r = k.hi - x;
+    if ((l >= kMinNormal) & (r >= kMinNormal) & (l < kInf) & (r < kInf)) {
+      s.px.mul(l);
+      s.pc.mul(r);
+      ++s.cnt;
+    } else {
+      s.exc += logpdf(x, k);
+    }
+  }
+  static M355_DEV double sum_finish(const SumAcc& s, const K& k) {
+    return (((k.a - 1.0) * s.px.log() + (k.b - 1.0) * s.pc.log()) - (double)s.cnt * k.c) + s.exc;
   }
   static M355_DEV double logpdf(double x, const K& k) {  // betascaled.py:106-112
     if ((x < k.lo) | (x > k.hi)) return -kInf;

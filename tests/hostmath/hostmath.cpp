@@ -2,6 +2,8 @@
 // continued fractions and root finders of csrc/m355_special.h be checked against SciPy while no
 // GPU is attached.  The hardware seeds (v_rcp_f64, v_frexp_*) and the device libm (lgamma, exp,
 // erfc) are replaced by host equivalents, so this is NOT the parity test: parity is tests -m gpu.
+#include <type_traits>
+
 #include "../../distributions_amd/csrc/m355_dist_list.h"
 #include "../../distributions_amd/csrc/m355_dists4.h"
 #include "../../distributions_amd/csrc/m355_grad.h"
@@ -54,11 +56,18 @@ template <int D> static int run_sum_acc(long n, const double* x, const double* p
   *out = DD::sum_finish(s, k);
   return 0;
 }
+template <class T, class = void> struct hm_has_sum_acc : std::false_type {};
+template <class T> struct hm_has_sum_acc<T, std::void_t<typename T::SumAcc>> : std::true_type {};
+template <int D> static int sum_acc_or_none(long n, const double* x, const double* p, double* out) {
+  if constexpr (hm_has_sum_acc<Dist<D>>::value) return run_sum_acc<D>(n, x, p, out);
+  else return -2;
+}
 extern "C" int hm_sum_acc(int dist, long n, const double* x, const double* p, double* out) {
   switch (dist) {
-    case M355_GAMMA: return run_sum_acc<M355_GAMMA>(n, x, p, out);
-    case M355_BETA: return run_sum_acc<M355_BETA>(n, x, p, out);
-    case M355_STUDENTT: return run_sum_acc<M355_STUDENTT>(n, x, p, out);
+#define HM_SUM(ID, name, np) \
+  case ID: return sum_acc_or_none<ID>(n, x, p, out);
+    M355_DIST_LIST(HM_SUM)
+#undef HM_SUM
   }
   return -1;
 }

@@ -196,6 +196,26 @@ def test_sumlogp_product_form_edges(gpu):
             assert abs(got - math.fsum(terms)) <= 1e-12 * float(np.sum(np.abs(terms))), (name, extra, got, exp)
         else:
             assert (math.isnan(exp) and math.isnan(got)) or got == exp, (name, extra, got, exp)
+    # the other families whose sum-logp kernel has the product form
+    import importlib
+    more = [("cauchy", (0.5, 2.0), 0.5 + 2.0 * rng.standard_cauchy(n), [np.inf]), ("halfcauchy", (3.5,), np.abs(3.5 * rng.standard_cauchy(n)), [-1.0]),
+            ("pareto", (2.5, 1.5), 1.5 * (1 + rng.pareto(2.5, n)), [1.0]), ("inversegamma", (3.0, 2.0), 2.0 / rng.gamma(3.0, 1.0, n), [0.0]),
+            ("chisquared", (7.0,), rng.chisquare(7.0, n), [-1.0]), ("scaledinversechisquared", (5.0, 0.7), 3.5 / rng.chisquare(5.0, n), [np.nan]),
+            ("betascaled", (2.0, 5.0, -1.0, 3.0), -1.0 + 4.0 * rng.beta(2, 5, n), [3.5])]
+    for name, params, x0, extra in more:
+        m = importlib.import_module(f"distributions_amd.{name}")
+        for ex in ([], extra):
+            x = x0.copy()
+            for j, e in enumerate(ex):
+                x[(j + 1) * 333_331] = e
+            with np.errstate(all="ignore"):
+                terms = R.TABLE[f"{name}_logpdf"](x, *params)
+                exp = float(np.sum(terms))
+            got = m.sum_logpdf(x, *params)
+            if math.isfinite(exp):
+                assert abs(got - math.fsum(terms)) <= 1e-12 * float(np.sum(np.abs(terms))), (name, ex, got, exp)
+            else:
+                assert (math.isnan(exp) and math.isnan(got)) or got == exp, (name, ex, got, exp)
     # gamma(alpha = 1): x = 0 contributes 0, not 0 * -inf (quirk Q2)
     x = np.concatenate([rng.gamma(1.0, 1.0, 100_000), [0.0]])
     t = R.gamma_logpdf(x, 1.0, 2.0)

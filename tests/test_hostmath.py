@@ -340,9 +340,19 @@ _SUM_ACC_CASES = [
     ("studentt", (1.0, 3.0, 0.01), lambda r, n: 3 + 0.01 * r.standard_t(1, n)),   # cauchy tails: 1 + w up to 1e30
     ("studentt", (2000.0, 0.0, 1.0), lambda r, n: 1e-9 * r.normal(size=n)),      # w ~ 1e-21: the side sum carries it
 ]
+_SUM_ACC_ONLY = [  # families with the product form on the sum-logp path only (no sufficient-statistics gradient)
+    ("cauchy", (0.5, 2.0), lambda r, n: 0.5 + 2.0 * r.standard_cauchy(n)),
+    ("halfcauchy", (3.5,), lambda r, n: np.abs(3.5 * r.standard_cauchy(n))),
+    ("pareto", (2.5, 1.5), lambda r, n: 1.5 * (1 + r.pareto(2.5, n))),
+    ("inversegamma", (3.0, 2.0), lambda r, n: 2.0 / r.gamma(3.0, 1.0, n)),
+    ("chisquared", (7.0,), lambda r, n: r.chisquare(7.0, n)),
+    ("chisquared", (2.0,), lambda r, n: r.chisquare(2.0, n)),
+    ("scaledinversechisquared", (5.0, 0.7), lambda r, n: 5.0 * 0.7 / r.chisquare(5.0, n)),
+    ("betascaled", (2.0, 5.0, -1.0, 3.0), lambda r, n: -1.0 + 4.0 * r.beta(2, 5, n)),
+]
 
 
-@pytest.mark.parametrize("name, params, draw", _SUM_ACC_CASES, ids=[f"{c[0]}-{c[1]}" for c in _SUM_ACC_CASES])
+@pytest.mark.parametrize("name, params, draw", _SUM_ACC_CASES + _SUM_ACC_ONLY, ids=[f"{c[0]}-{c[1]}" for c in _SUM_ACC_CASES + _SUM_ACC_ONLY])
 def test_host_sum_acc_vs_fsum(hostlib, name, params, draw):
     """Dist<>::SumAcc (sum of logpdf with sums of logarithms carried as products, csrc/m355_math.h LogProd)
     against math.fsum of the oracle's logpdf terms: 1e-12 * sum |term|."""
@@ -365,9 +375,16 @@ def test_host_sum_acc_exceptional_elements(hostlib):
     rng = np.random.default_rng(78)
     base = {"gamma": ((2.5, 1.3), rng.gamma(2.5, 1.0, 1000)), "beta": ((2.0, 5.0), rng.beta(2, 5, 1000)),
             "studentt": ((5.0, 0.0, 2.0), rng.standard_t(5, 1000))}
+    for nm, pr, draw in _SUM_ACC_ONLY:
+        base[nm] = (pr, draw(rng, 1000))
     for name, extra in (("gamma", [0.0]), ("gamma", [-1.0]), ("gamma", [5e-324, 1e-310]), ("gamma", [np.inf]), ("gamma", [np.nan]),
                         ("beta", [0.0]), ("beta", [1.0]), ("beta", [1.5]), ("beta", [1e-320]), ("beta", [np.nan, -1.0]),
-                        ("studentt", [np.inf]), ("studentt", [1e200, -1e200]), ("studentt", [np.nan])):
+                        ("studentt", [np.inf]), ("studentt", [1e200, -1e200]), ("studentt", [np.nan]),
+                        ("cauchy", [np.inf]), ("cauchy", [1e300, np.nan]), ("halfcauchy", [-1.0]), ("halfcauchy", [0.0, np.inf]),
+                        ("pareto", [1.0]), ("pareto", [np.inf]), ("pareto", [-2.0, np.nan]), ("inversegamma", [0.0]), ("inversegamma", [-1.0, 1e-310]),
+                        ("inversegamma", [np.inf]), ("chisquared", [0.0]), ("chisquared", [-1.0]), ("chisquared", [np.inf]),
+                        ("scaledinversechisquared", [0.0, 5e-324]), ("scaledinversechisquared", [np.inf, np.nan]),
+                        ("betascaled", [-1.0]), ("betascaled", [3.0]), ("betascaled", [3.5, -2.0]), ("betascaled", [np.nan])):
         params, x0 = base[name]
         x = np.concatenate([x0[:500], extra, x0[500:]])
         with np.errstate(all="ignore"):
