@@ -166,7 +166,7 @@ template <> struct Dist<M355_BETA> {
   static constexpr int NP = 2;
   static constexpr bool kLogTable = true;  // logpdf uses flog_tab
   struct K {
-    double a, b, am1, bm1, lbeta;
+    double a, b, am1, bm1, lbeta, ihalf;  // ihalf = I_{1/2}(a, b), for betaincinv_
   };
   static M355_HD K derive(const double* p) {
     K k;
@@ -176,6 +176,7 @@ template <> struct Dist<M355_BETA> {
     k.bm1 = p[1] - 1.0;
     // pytensor.tensor.special.betaln (lgamma(a)+lgamma(b)-lgamma(a+b)), cancellation-free form
     k.lbeta = lbeta_(p[0], p[1]);
+    k.ihalf = betainc_half(p[0], p[1], k.lbeta);
     return k;
   }
   // beta.py:102-108; xlogy0(alpha+beta-1, 1) is a*log(1) == 0 (or the xlogy0 zero).
@@ -232,7 +233,7 @@ template <> struct Dist<M355_BETA> {
     if constexpr (FN == M355_SF) return exp_(logsf(x, k));    // beta.py:82-83
     if constexpr (FN == M355_PPF || FN == M355_ISF) {         // beta.py:78-79, 70-71
       const double q = (FN == M355_ISF) ? 1.0 - x : x;
-      return ppf_bounds_cont(betaincinv_(k.a, k.b, q, k.lbeta), q, 0.0, 1.0);
+      return ppf_bounds_cont(betaincinv_(k.a, k.b, q, k.lbeta, k.ihalf), q, 0.0, 1.0);
     }
     return kNaN;
   }
@@ -244,7 +245,7 @@ template <> struct Dist<M355_STUDENTT> {
   static constexpr int NP = 3;
   static constexpr bool kLogTable = true;  // logpdf uses flog1p_tab
   struct K {
-    double nu, mu, sigma, c, hnp1, inv_s2nu, lbeta_h;  // lbeta_h = betaln(nu/2, 1/2)
+    double nu, mu, sigma, c, hnp1, inv_s2nu, lbeta_h, ihalf_h;  // lbeta_h = betaln(nu/2, 1/2), ihalf_h = I_{1/2}(nu/2, 1/2)
   };
   static M355_HD K derive(const double* p) {
     K k;
@@ -257,6 +258,7 @@ template <> struct Dist<M355_STUDENTT> {
     k.hnp1 = 0.5 * (p[0] + 1.0);
     k.inv_s2nu = 1.0 / (p[2] * p[2] * p[0]);
     k.lbeta_h = lbeta_(0.5 * p[0], 0.5);
+    k.ihalf_h = betainc_half(0.5 * p[0], 0.5, k.lbeta_h);
     return k;
   }
   // studentt.py:108-119.  The nu > 1e5 arm is normal.LOGCDF(x, mu, sigma): the reference binds
@@ -306,7 +308,7 @@ template <> struct Dist<M355_STUDENTT> {
       r = 0.0;
     } else {
       const double qq = (q < 0.5) ? 2.0 * q : 2.0 * (1.0 - q);
-      const double b = betaincinv_(0.5 * k.nu, 0.5, qq, k.lbeta_h);
+      const double b = betaincinv_(0.5 * k.nu, 0.5, qq, k.lbeta_h, k.ihalf_h);
       const double t = sqrt_(k.nu) * sqrt_(1.0 / b - 1.0);
       r = (q < 0.5) ? -t : t;
     }

@@ -741,7 +741,7 @@ template <> struct Dist<M355_SCALEDINVERSECHISQUARED> {
 template <> struct Dist<M355_HALFSTUDENTT> {
   static constexpr int kBinned = 1;
   static constexpr int NP = 2;
-  struct K { double nu, sigma, logsigma, c, lbeta_h; };
+  struct K { double nu, sigma, logsigma, c, lbeta_h, ihalf_h; };
   static M355_HD K derive(const double* p) {
     K k;
     k.nu = p[0];
@@ -749,6 +749,7 @@ template <> struct Dist<M355_HALFSTUDENTT> {
     k.logsigma = flog(p[1]);
     k.c = ((lgamma_((p[0] + 1.0) / 2.0) - lgamma_(p[0] / 2.0)) - 0.5 * flog(p[0] * kPi * (p[1] * p[1]))) + kLog2;
     k.lbeta_h = lbeta_(0.5 * p[0], 0.5);
+    k.ihalf_h = betainc_half(0.5 * p[0], 0.5, k.lbeta_h);
     return k;
   }
   static M355_DEV double cdf(double x, const K& k) {  // halfstudentt.py:76-83
@@ -774,8 +775,8 @@ template <> struct Dist<M355_HALFSTUDENTT> {
       const double q = (FN == M355_ISF) ? 1.0 - x : x;
       const double qf = (q + 1.0) / 2.0;
       double v;
-      if (qf < 0.5) v = betaincinv_(0.5 * k.nu, 0.5, 2.0 * qf, k.lbeta_h);
-      else v = sqrt_(k.nu / betaincinv_(0.5 * k.nu, 0.5, 2.0 - 2.0 * qf, k.lbeta_h) - k.nu);
+      if (qf < 0.5) v = betaincinv_(0.5 * k.nu, 0.5, 2.0 * qf, k.lbeta_h, k.ihalf_h);
+      else v = sqrt_(k.nu / betaincinv_(0.5 * k.nu, 0.5, 2.0 - 2.0 * qf, k.lbeta_h, k.ihalf_h) - k.nu);
       return ppf_bounds_cont(v * k.sigma, q, 0.0, kInf);
     }
     return kNaN;
@@ -787,7 +788,7 @@ template <> struct Dist<M355_BETASCALED> {
   static constexpr int kBinned = 1;
   static constexpr int NP = 4;
   static constexpr bool kLogTable = true;  // logpdf uses flog_tab
-  struct K { double a, b, lo, hi, w, lbeta, c; };  // c = xlogy0(a+b-1, hi-lo) + betaln(a, b)
+  struct K { double a, b, lo, hi, w, lbeta, c, ihalf; };  // c = xlogy0(a+b-1, hi-lo) + betaln(a, b); ihalf = I_{1/2}(a, b)
   static M355_HD K derive(const double* p) {
     K k;
     k.a = p[0];
@@ -797,6 +798,7 @@ template <> struct Dist<M355_BETASCALED> {
     k.w = p[3] - p[2];
     k.lbeta = lbeta_(p[0], p[1]);
     k.c = xlogy0_l(p[0] + p[1] - 1.0, flog(p[3] - p[2])) + k.lbeta;
+    k.ihalf = betainc_half(p[0], p[1], k.lbeta);
     return k;
   }
   // sum of logpdf: sum log(x - lo), sum log(hi - x) as LogProds (protocol of Dist<M355_GAMMA>::SumAcc)
@@ -847,7 +849,7 @@ template <> struct Dist<M355_BETASCALED> {
     }
     if constexpr (FN == M355_PPF || FN == M355_ISF) {  // betascaled.py:83-85, 75-76
       const double q = (FN == M355_ISF) ? 1.0 - x : x;
-      return ppf_bounds_cont(betaincinv_(k.a, k.b, q, k.lbeta) * k.w + k.lo, q, k.lo, k.hi);
+      return ppf_bounds_cont(betaincinv_(k.a, k.b, q, k.lbeta, k.ihalf) * k.w + k.lo, q, k.lo, k.hi);
     }
     return kNaN;
   }

@@ -228,7 +228,7 @@ template <> struct Dist<M355_TRUNCATEDNORMAL> {
 template <> struct Dist<M355_SKEW_STUDENTT> {
   static constexpr int kBinned = 1;
   static constexpr int NP = 4;
-  struct K { double a, b, mu, sigma, ab, sqab, lbeta, c; };  // c = (a+b-1) log 2 + betaln + 0.5 log(a+b) + log sigma
+  struct K { double a, b, mu, sigma, ab, sqab, lbeta, c, ihalf; };  // c = (a+b-1) log 2 + betaln + 0.5 log(a+b) + log sigma; ihalf = I_{1/2}(a, b)
   static M355_HD K derive(const double* p) {
     K k;
     k.a = p[0];
@@ -239,6 +239,7 @@ template <> struct Dist<M355_SKEW_STUDENTT> {
     k.sqab = ::sqrt(k.ab);
     k.lbeta = lbeta_(p[0], p[1]);
     k.c = (((k.ab - 1.0) * kLog2 + k.lbeta) + 0.5 * flog(k.ab)) + flog(p[3]);
+    k.ihalf = betainc_half(p[0], p[1], k.lbeta);
     return k;
   }
   static M355_DEV double logpdf(double x, const K& k) {  // skew_studentt.py:113-120
@@ -264,7 +265,7 @@ template <> struct Dist<M355_SKEW_STUDENTT> {
     if constexpr (FN == M355_LOGSF) return flog(cdf_raw(-x, k.b, k.a, -k.mu, k));
     if constexpr (FN == M355_PPF || FN == M355_ISF) {  // skew_studentt.py:150-157, 160-161
       const double q = (FN == M355_ISF) ? 1.0 - x : x;
-      const double bv = betaincinv_(k.a, k.b, q, k.lbeta);
+      const double bv = betaincinv_(k.a, k.b, q, k.lbeta, k.ihalf);
       const double z = ((2.0 * bv - 1.0) * k.sqab) / (2.0 * sqrt_(bv * (1.0 - bv)));
       return ppf_bounds_cont(k.mu + k.sigma * z, q, -kInf, kInf);
     }

@@ -16,7 +16,7 @@ constexpr double kMaxLog = 709.782712893384;
 constexpr double kMinLog = -745.13321910194122;
 
 #if defined(__HIPCC__)
-M355_DEV double exp_(double x) { return ::exp(x); }
+M355_HD double exp_(double x) { return ::exp(x); }
 M355_DEV double expm1_(double x) { return ::expm1(x); }
 M355_HD_HEAVY double lgamma_(double x) { return ::lgamma(x); }
 M355_DEV double erf_(double x) { return ::erf(x); }
@@ -375,13 +375,13 @@ M355_DEV_HEAVY double gammaincinv_p(double a, double p, double lga) {
 // ------------------------------------------------------------------------------------------------
 // log( x^a (1-x)^b / B(a,b) ) with y = 1 - x supplied separately (so that callers that know 1-x
 // exactly keep it).  lbeta = lgamma(a)+lgamma(b)-lgamma(a+b).
-M355_DEV double log_beta_kernel(double a, double b, double x, double y, double lbeta) {
+M355_HD double log_beta_kernel(double a, double b, double x, double y, double lbeta) {
   return a * flog(x) + b * flog(y) - lbeta;
 }
 
 // Power series for I_x(a,b), good when b*x <= 1 and x <= 0.95 (DLMF 8.17.8 rearranged):
 //   I_x = x^a/B(a,b) * [ 1/a + sum_{n>=1} (1-b)(2-b)...(n-b) x^n / (n! (a+n)) ].
-M355_DEV_HEAVY double betainc_pseries(double a, double b, double x, double lbeta) {
+M355_HD_HEAVY double betainc_pseries(double a, double b, double x, double lbeta) {
   const double ai = fdiv(1.0, a);
   double t = (1.0 - b) * x;
   double v = fdiv(t, a + 1.0);
@@ -409,7 +409,7 @@ M355_DEV_HEAVY double betainc_pseries(double a, double b, double x, double lbeta
 // numerators' denominators (a_k' = D_{k-1} N_k, b_k' = D_k for a_k = N_k / D_k, b_k = 1): no division inside a step,
 // one per pair of steps for the convergence test, renormalised by a power of two after every pair.  Returns the fraction
 // value (without the x^a(1-x)^b/(a B) prefactor).
-M355_DEV_HEAVY double betainc_cf(double a, double b, double x) {
+M355_HD_HEAVY double betainc_cf(double a, double b, double x) {
   const double qab = a + b, qam = a - 1.0;
   // A_{-1} = 1, B_{-1} = 0, A_0 = b_0 = 1, B_0 = 1 for the fraction 1 / (1 + d_1 / (1 + d_2 / (1 + ...))):
   // evaluate f = 1 + d_1/(1 + d_2/(...)) and return 1 / f
@@ -448,7 +448,7 @@ M355_DEV_HEAVY double betainc_cf(double a, double b, double x) {
 }
 
 // Regularised incomplete beta I_x(a,b) (pt.betainc).  `y` must be 1-x; lbeta = betaln(a,b).
-M355_DEV_HEAVY double betainc_xy(double a, double b, double x, double y, double lbeta) {
+M355_HD_HEAVY double betainc_xy(double a, double b, double x, double y, double lbeta) {
   if (!(a > 0.0) || !(b > 0.0) || !(x >= 0.0) || !(x <= 1.0)) return kNaN;
   if (x == 0.0) return 0.0;
   if (y == 0.0) return 1.0;  // (x may have rounded to 1 while y is still a tiny positive number)
@@ -478,6 +478,9 @@ M355_DEV_HEAVY double betainc_xy(double a, double b, double x, double y, double 
 M355_DEV double betainc_(double a, double b, double x, double lbeta) {
   return betainc_xy(a, b, x, 1.0 - x, lbeta);
 }
+// I_{1/2}(a, b): which half of [0, 1] the root of I_x(a, b) = p lies in.  Depends on the parameters only, so
+// Dist<>::derive computes it once per launch (host) or LDS table entry and hands it to betaincinv_.
+M355_HD double betainc_half(double a, double b, double lbeta) { return betainc_xy(a, b, 0.5, 0.5, lbeta); }
 
 // Initial guess for I_x(a,b) = p, p <= 1/2 (power-law tail or A&S 26.5.22).
 M355_DEV double betaincinv_guess(double a, double b, double p, double lbeta) {
@@ -497,12 +500,13 @@ M355_DEV double betaincinv_guess(double a, double b, double p, double lbeta) {
 
 // Inverse of I_.(a,b) (pytensor.tensor.math.betaincinv).  The iterate t is x when the root is
 // <= 1/2 and y = 1-x otherwise (full relative accuracy of whichever is small).  Safeguarded Newton/Halley, with Newton on log(tail) while the tail is far below 1.
-M355_DEV_HEAVY double betaincinv_(double a, double b, double p, double lbeta) {
+// ihalf = betainc_half(a, b, lbeta) if the caller has it (NaN: evaluated here).
+M355_DEV_HEAVY double betaincinv_(double a, double b, double p, double lbeta, double ihalf = kNaN) {
   if (!(a > 0.0) || !(b > 0.0) || !(p >= 0.0) || !(p <= 1.0)) return kNaN;
   if (p == 0.0) return 0.0;
   if (p == 1.0) return 1.0;
   if (a == b && p == 0.5) return 0.5;  // the symmetric median, exactly (skew_studentt.ppf(0.5; a = b) must be mu)
-  const bool rep_y = p > betainc_xy(a, b, 0.5, 0.5, lbeta);
+  const bool rep_y = p > ((ihalf == ihalf) ? ihalf : betainc_xy(a, b, 0.5, 0.5, lbeta));
   // Equation: I_x(a,b) = p for p <= 1/2, else I_y(b,a) = 1-p (exact), so that the small tail
   // keeps full relative accuracy; betainc_xy takes x and y separately, so either equation can
   // be evaluated from either iterate.
