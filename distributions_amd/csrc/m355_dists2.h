@@ -282,12 +282,14 @@ template <> struct Dist<M355_GUMBEL> {
 // -------------------------------------------------------------------------------------- weibull
 template <> struct Dist<M355_WEIBULL> {
   static constexpr int NP = 2;
+  static constexpr bool kLogTable = true;  // logpdf: one table log shared by log(z) and z**alpha
   struct K { double alpha, beta, c; };
   static M355_HD K derive(const double* p) { return K{p[0], p[1], flog(p[0] / p[1])}; }
   static M355_DEV double logpdf(double x, const K& k) {  // weibull.py:82-87
     if (x < 0.0) return -kInf;
     const double z = x / k.beta;
-    return (k.c + xlogy0_l(k.alpha - 1.0, flog(z))) - pow_(z, k.alpha);
+    const double lz = flog_tab(z);
+    return (k.c + xlogy0_l(k.alpha - 1.0, lz)) - pow_l(z, lz, k.alpha);
   }
   static M355_DEV double logcdf(double x, const K& k) {  // weibull.py:72-79
     return (x < 0.0) ? -kInf : log1mexp_(-pow_(x / k.beta, k.alpha));
@@ -428,11 +430,13 @@ template <> struct Dist<M355_TRIANGULAR> {
 // ---------------------------------------------------------------------------------- kumaraswamy
 template <> struct Dist<M355_KUMARASWAMY> {
   static constexpr int NP = 2;
+  static constexpr bool kLogTable = true;  // logpdf: table logs, log(x) shared with x**a
   struct K { double a, b, logab; };
   static M355_HD K derive(const double* p) { return K{p[0], p[1], flog(p[0] * p[1])}; }
   static M355_DEV double logpdf(double x, const K& k) {  // kumaraswamy.py:80-85
     if ((x <= 0.0) | (x >= 1.0)) return -kInf;
-    return (k.logab + xlogy0_l(k.a - 1.0, flog(x))) + xlogy0_l(k.b - 1.0, flog(1.0 - pow_(x, k.a)));
+    const double lx = flog_tab(x);
+    return (k.logab + xlogy0_l(k.a - 1.0, lx)) + xlogy0_l(k.b - 1.0, flog_tab(1.0 - pow_l(x, lx, k.a)));
   }
   template <int FN> static M355_DEV double eval(double x, const K& k) {
     if constexpr (FN == M355_LOGPDF) return logpdf(x, k);
@@ -522,13 +526,15 @@ template <> struct Dist<M355_ASYMMETRICLAPLACE> {
 // ---------------------------------------------------------------------------------- loglogistic
 template <> struct Dist<M355_LOGLOGISTIC> {
   static constexpr int NP = 2;
+  static constexpr bool kLogTable = true;  // logpdf: table logs, log(z) shared with z**beta
   struct K { double alpha, beta, c; };
   static M355_HD K derive(const double* p) { return K{p[0], p[1], flog(p[1]) - flog(p[0])}; }
   static M355_DEV double logpdf(double x, const K& k) {  // loglogistic.py:70-73
     if (x <= 0.0) return -kInf;
     if (x == kInf) return -kInf;
     const double z = x / k.alpha;
-    return (k.c + (k.beta - 1.0) * flog(z)) - 2.0 * flog1p(pow_(z, k.beta));
+    const double lz = flog_tab(z);
+    return (k.c + (k.beta - 1.0) * lz) - 2.0 * flog1p_tab(pow_l(z, lz, k.beta));
   }
   template <int FN> static M355_DEV double eval(double x, const K& k) {
     if constexpr (FN == M355_LOGPDF) return logpdf(x, k);

@@ -587,6 +587,7 @@ struct MomentArgs {
 
 template <int D>
 __global__ __launch_bounds__(kBlock) void k_moment_thread(GenericOps ops, int stat, void* __restrict__ out, int odt, long long n) {
+  if constexpr (uses_log_table<Dist<D>>::value) log_table_init();  // integrands / medians may call flog_tab bodies
   const bool small = n <= 0xffffffffll;
   for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < n; i += (long long)gridDim.x * kBlock) {
     double pp[kMaxParams] = {0.0, 0.0, 0.0, 0.0};
@@ -598,6 +599,7 @@ __global__ __launch_bounds__(kBlock) void k_moment_thread(GenericOps ops, int st
 
 template <int D>
 __global__ __launch_bounds__(kBlock) void k_moment_wave(GenericOps ops, int stat, void* __restrict__ out, int odt, long long n) {
+  if constexpr (uses_log_table<Dist<D>>::value) log_table_init();  // integrands / medians may call flog_tab bodies
   const bool small = n <= 0xffffffffll;
   const long long wave = ((long long)blockIdx.x * kBlock + threadIdx.x) >> 6, nwaves = ((long long)gridDim.x * kBlock) >> 6;
   for (long long i = wave; i < n; i += nwaves) {  // uniform per wavefront: every lane reaches the shuffles

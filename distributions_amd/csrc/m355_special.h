@@ -35,6 +35,13 @@ M355_DEV double pow_(double x, double y) {
 }
 M355_DEV double atan_(double x) { return ::atan(x); }
 M355_DEV double tan_(double x) { return ::tan(x); }
+// x**y where the caller already holds lx = log(x) (bodies that need both log(x) and x**y: weibull, loglogistic,
+// kumaraswamy): one exp on the common path, ocml's pow for the special cases as in pow_.
+M355_DEV double pow_l(double x, double lx, double y) {
+  const unsigned hx = (unsigned)(__builtin_bit_cast(unsigned long long, x) >> 32);
+  if ((hx - 0x00100000u) < 0x7fe00000u) return ::exp(y * lx);
+  return ::pow(x, y);
+}
 #else
 M355_DEV double exp_(double x) { return std::exp(x); }
 M355_DEV double expm1_(double x) { return std::expm1(x); }
@@ -59,6 +66,7 @@ M355_DEV double floor_(double x) { return std::floor(x); }
 M355_DEV double pow_(double x, double y) { return std::pow(x, y); }
 M355_DEV double atan_(double x) { return std::atan(x); }
 M355_DEV double tan_(double x) { return std::tan(x); }
+M355_DEV double pow_l(double x, double lx, double y) { (void)lx; return std::pow(x, y); }
 #endif
 
 // pt.log1mexp: log(1 - exp(x)) for x <= 0.
