@@ -229,11 +229,12 @@ template <> struct Dist<M355_LAPLACE> {
 // ------------------------------------------------------------------------------------- logistic
 template <> struct Dist<M355_LOGISTIC> {
   static constexpr int NP = 2;
+  static constexpr bool kLogTable = true;  // logpdf uses flog1p_tab
   struct K { double mu, s, logs; };
   static M355_HD K derive(const double* p) { return K{p[0], p[1], flog(p[1])}; }
   static M355_DEV double logpdf(double x, const K& k) {  // logistic.py:74-76
     const double z = (x - k.mu) / k.s;
-    return (x == -kInf) ? -kInf : (-k.logs - z) - 2.0 * flog1p(exp_(-z));
+    return (x == -kInf) ? -kInf : (-k.logs - z) - 2.0 * flog1p_tab(exp_(-z));
   }
   template <int FN> static M355_DEV double eval(double x, const K& k) {
     if constexpr (FN == M355_LOGPDF) return logpdf(x, k);
@@ -554,13 +555,15 @@ template <> struct Dist<M355_LOGLOGISTIC> {
 // ---------------------------------------------------------------------------------- logitnormal
 template <> struct Dist<M355_LOGITNORMAL> {
   static constexpr int NP = 2;
+  static constexpr bool kLogTable = true;  // logpdf uses flog_tab / flog1p_tab
   struct K { double mu, sigma, c; };
   static M355_HD K derive(const double* p) { return K{p[0], p[1], -flog(p[1]) - kHalfLog2Pi}; }
   static M355_DEV double logit(double x) { return flog(x) - flog1p(-x); }  // logitnormal.py:11-12
   static M355_DEV double logpdf(double x, const K& k) {                    // logitnormal.py:122-132
     if ((x <= 0.0) | (x >= 1.0)) return -kInf;
-    const double z = (logit(x) - k.mu) / k.sigma;
-    return ((-0.5 * (z * z) + k.c) - flog(x)) - flog1p(-x);
+    const double lx = flog_tab(x), lc = flog1p_tab(-x);  // 0 < x < 1: 1 - x is exact above 1/2, corrected below
+    const double z = ((lx - lc) - k.mu) / k.sigma;
+    return ((-0.5 * (z * z) + k.c) - lx) - lc;
   }
   static M355_DEV double logcdf(double x, const K& k) {  // logitnormal.py:141-156
     if (x <= 0.0) return -kInf;

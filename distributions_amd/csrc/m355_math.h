@@ -245,7 +245,8 @@ M355_HD double flog_tab(double x) {
   res = res + log_c;
   return __builtin_fma(ef, sconst(kLn2Hi), res);
 }
-// log(1 + w), w >= 0, on the table log (same correction as flog1p_stream)
+// log(1 + w), w > -1, on the table log (same correction as flog1p_stream; for w < 0 the sum 1 + w is exact
+// below -1/2 and the first-order correction c (2 - u) ~ c / u holds to 3e-17 above it)
 M355_HD double flog1p_tab(double w) {
   const double u = 1.0 + w;
   const double c = w - (u - 1.0);
