@@ -49,6 +49,15 @@ def config2(torch, n):
             print(json.dumps({"config": 2, "fn": f"{name}.{fn}", "n": n, "layout": "scalar params", "ms": ms,
                               "evals_per_s": n / (ms * 1e-3), "GB_per_s_algorithmic": 16.0 * n / (ms * 1e-3) / 1e9}),
                   flush=True)
+    # float32 in, float32 out (8 B per element; the arithmetic stays fp64, tolerance 1e-5)
+    out32 = torch.empty(n, dtype=torch.float32, device=dev)
+    for name in ("normal", "gamma", "beta"):
+        x32 = xs[name].to(torch.float32)
+        ms = timed(torch, lambda: raw.elemwise_into(name, "logpdf", x32, params[name], out32), reps=5)
+        print(json.dumps({"config": 2, "fn": f"{name}.logpdf", "n": n, "layout": "scalar params, float32 in / out", "ms": ms,
+                          "evals_per_s": n / (ms * 1e-3), "GB_per_s_algorithmic": 8.0 * n / (ms * 1e-3) / 1e9}), flush=True)
+        del x32
+    del out32
     # broadcast params: x viewed as (n/1024, 1024), params of shape (1024,) staged in LDS
     from distributions_amd import gamma, normal
 

@@ -63,13 +63,14 @@ typedef double d2_t __attribute__((ext_vector_type(2)));
 typedef float f2_t __attribute__((ext_vector_type(2)));
 typedef long long l2_t __attribute__((ext_vector_type(2)));
 
-template <bool F64IO> M355_DEV void load2(const void* p, int dt, long long i, double& a, double& b) {
-  if (F64IO || dt == M355_F64) {
+// IO: 1 = float64 in and out, 2 = float32 in and out (compile-time), 0 = dtype switch per access (wave-uniform)
+template <int IO> M355_DEV void load2(const void* p, int dt, long long i, double& a, double& b) {
+  if (IO == 1 || (IO == 0 && dt == M355_F64)) {
     // streamed once: non-temporal (+8-10 % over default-policy loads/stores, tools/stream_tune.hip)
     const d2_t v = __builtin_nontemporal_load(reinterpret_cast<const d2_t*>(static_cast<const double*>(p) + i));
     a = v.x;
     b = v.y;
-  } else if (dt == M355_F32) {
+  } else if (IO == 2 || dt == M355_F32) {
     const f2_t v = __builtin_nontemporal_load(reinterpret_cast<const f2_t*>(static_cast<const float*>(p) + i));
     a = (double)v.x;
     b = (double)v.y;
@@ -79,8 +80,8 @@ template <bool F64IO> M355_DEV void load2(const void* p, int dt, long long i, do
     b = (double)v.y;
   }
 }
-template <bool F64IO> M355_DEV void store2(void* p, int dt, long long i, double a, double b) {
-  if (F64IO || dt == M355_F64) {
+template <int IO> M355_DEV void store2(void* p, int dt, long long i, double a, double b) {
+  if (IO == 1 || (IO == 0 && dt == M355_F64)) {
     d2_t v;
     v.x = a;
     v.y = b;
@@ -128,11 +129,9 @@ template <class T, class = void> struct has_sum_acc : std::false_type {};
 template <class T> struct has_sum_acc<T, std::void_t<typename T::SumAcc>> : std::true_type {};
 constexpr int kRenormEvery = 64;  // tiles (4 elements per thread each) between LogProd renormalisations
 
-template <int D, int FN, bool REDUCE, bool F64IO>
-__global__ __launch_bounds__(kBlock) void k_scalar(const void* __restrict__ x, int xdt,
-                                                   void* __restrict__ out, int odt, long long n,
-                                                   const typename Dist<D>::K k,
-                                                   double* __restrict__ partials) {
+template <int D, int FN, bool REDUCE, int IO>
+M355_DEV void scalar_body(const void* __restrict__ x, int xdt, void* __restrict__ out, int odt, long long n,
+                          const typename Dist<D>::K& k, double* __restrict__ partials) {
   using DD = Dist<D>;
   if constexpr (uses_log_table<DD>::value) log_table_init();
   const long long ntiles = n / kTile;
@@ -145,7 +144,7 @@ __global__ __launch_bounds__(kBlock) void k_scalar(const void* __restrict__ x, i
         const long long base = tile * kTile + threadIdx.x * kVec;
         double v[kUnroll][kVec];
 #pragma unroll
-        for (int u = 0; u < kUnroll; ++u) load2<F64IO>(x, xdt, base + u * (kBlock * kVec), v[u][0], v[u][1]);
+        for (int u = 0; u < kUnroll; ++u) load2<IO>(x, xdt, base + u * (kBlock * kVec), v[u][0], v[u][1]);
 #pragma unroll
         for (int u = 0; u < kUnroll; ++u) {
           DD::sum_add(s, v[u][0], k);
@@ -168,7 +167,7 @@ __global__ __launch_bounds__(kBlock) void k_scalar(const void* __restrict__ x, i
     const long long base = tile * kTile + threadIdx.x * kVec;
     double v[kUnroll][kVec];
 #pragma unroll
-    for (int u = 0; u < kUnroll; ++u) load2<F64IO>(x, xdt, base + u * (kBlock * kVec), v[u][0], v[u][1]);
+    for (int u = 0; u < kUnroll; ++u) load2<IO>(x, xdt, base + u * (kBlock * kVec), v[u][0], v[u][1]);
 #pragma unroll
     for (int u = 0; u < kUnroll; ++u) {
       v[u][0] = DD::template eval<FN>(v[u][0], k);
@@ -176,7 +175,7 @@ __global__ __launch_bounds__(kBlock) void k_scalar(const void* __restrict__ x, i
       if constexpr (REDUCE) {
         acc += v[u][0] + v[u][1];
       } else {
-        store2<F64IO>(out, odt, base + u * (kBlock * kVec), v[u][0], v[u][1]);
+        store2<IO>(out, odt, base + u * (kBlock * kVec), v[u][0], v[u][1]);
       }
     }
   }
@@ -192,6 +191,20 @@ __global__ __launch_bounds__(kBlock) void k_scalar(const void* __restrict__ x, i
   }
 }
 
+template <int D, int FN, bool REDUCE, bool F64IO>
+__global__ __launch_bounds__(kBlock) void k_scalar(const void* __restrict__ x, int xdt,
+                                                   void* __restrict__ out, int odt, long long n,
+                                                   const typename Dist<D>::K k,
+                                                   double* __restrict__ partials) {
+  scalar_body<D, FN, REDUCE, F64IO ? 1 : 0>(x, xdt, out, odt, n, k, partials);
+}
+// logpdf with float32 in and out (8 B per element: the HBM-bound case at half the bytes), dtype fixed at compile time
+template <int D, bool REDUCE>
+__global__ __launch_bounds__(kBlock) void k_scalar_f32(const void* __restrict__ x, void* __restrict__ out, long long n,
+                                                       const typename Dist<D>::K k, double* __restrict__ partials) {
+  scalar_body<D, M355_LOGPDF, REDUCE, 2>(x, M355_F32, out, M355_F32, n, k, partials);
+}
+
 struct PeriodicParams {
   const double* ptr[kMaxParams];  // NULL: scalar
   double scalar[kMaxParams];
@@ -202,6 +215,7 @@ __global__ __launch_bounds__(kBlock) void k_periodic(const void* __restrict__ x,
                                                      void* __restrict__ out, int odt, long long n,
                                                      PeriodicParams pa, unsigned P,
                                                      double* __restrict__ partials) {
+  constexpr int IO = F64IO ? 1 : 0;
   using DD = Dist<D>;
   using K = typename DD::K;
   constexpr int NK = sizeof(K) / sizeof(double);
@@ -234,7 +248,7 @@ __global__ __launch_bounds__(kBlock) void k_periodic(const void* __restrict__ x,
     const long long base = tile * kTile + threadIdx.x * kVec;
     double v[kUnroll][kVec];
 #pragma unroll
-    for (int u = 0; u < kUnroll; ++u) load2<F64IO>(x, xdt, base + u * (kBlock * kVec), v[u][0], v[u][1]);
+    for (int u = 0; u < kUnroll; ++u) load2<IO>(x, xdt, base + u * (kBlock * kVec), v[u][0], v[u][1]);
     unsigned idx = idx0;
 #pragma unroll
     for (int u = 0; u < kUnroll; ++u) {
@@ -245,7 +259,7 @@ __global__ __launch_bounds__(kBlock) void k_periodic(const void* __restrict__ x,
       if constexpr (REDUCE) {
         acc += v[u][0] + v[u][1];
       } else {
-        store2<F64IO>(out, odt, base + u * (kBlock * kVec), v[u][0], v[u][1]);
+        store2<IO>(out, odt, base + u * (kBlock * kVec), v[u][0], v[u][1]);
       }
       idx += u_step;
       idx = idx >= P ? idx - P : idx;
@@ -298,7 +312,7 @@ __global__ __launch_bounds__(kBlock) void k_binned(const void* __restrict__ x, i
     unsigned long long key[kBinPer];
     unsigned long long kmin = ~0ull, kmax = 0ull;
 #pragma unroll
-    for (int j = 0; j < kBinPer; j += 2) load2<false>(x, xdt, base + (long long)(j / 2) * (kBlock * 2) + t * 2, v[j], v[j + 1]);
+    for (int j = 0; j < kBinPer; j += 2) load2<0>(x, xdt, base + (long long)(j / 2) * (kBlock * 2) + t * 2, v[j], v[j + 1]);
     // scale of the tile: mean |x| over its finite elements
     double sabs = 0.0, cfin = 0.0;
 #pragma unroll
@@ -395,7 +409,7 @@ __global__ __launch_bounds__(kBlock) void k_binned(const void* __restrict__ x, i
 #pragma unroll
     for (int j = 0; j < kBinPer; j += 2) {
       const int local = (j / 2) * (kBlock * 2) + t * 2;
-      store2<false>(out, odt, base + local, res[local], res[local + 1]);
+      store2<0>(out, odt, base + local, res[local], res[local + 1]);
     }
     __syncthreads();
   }
@@ -512,6 +526,13 @@ template <int D, int FN, bool REDUCE> int launch_fn(const LaunchArgs& a) {
           const int bb = (int)(bt > kMaxBlocks ? kMaxBlocks : bt);
           hipLaunchKernelGGL((k_binned<D, FN>), dim3(bb), dim3(kBlock), 0, a.stream, a.x.ptr, a.x.dtype, a.out,
                              a.out_dtype, n, k);
+          return (int)hipGetLastError();
+        }
+      }
+      if constexpr (FN == M355_LOGPDF) {
+        if (a.x.dtype == M355_F32 && (REDUCE || a.out_dtype == M355_F32)) {
+          hipLaunchKernelGGL((k_scalar_f32<D, REDUCE>), dim3(blocks), dim3(kBlock), 0, a.stream, a.x.ptr, a.out, n, k,
+                             a.partials);
           return (int)hipGetLastError();
         }
       }

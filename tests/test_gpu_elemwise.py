@@ -170,6 +170,27 @@ def test_sumlogp(gpu):
     assert abs(gamma.sum_logpdf(xr, a_row, 1.1) - math.fsum(terms.ravel())) <= 1e-12 * float(np.abs(terms).sum())
 
 
+def test_float32_kernels(gpu):
+    """float32 in / out logpdf (compile-time dtype kernel k_scalar_f32) and float32 data into the sum-logp kernel:
+    tolerance 1e-5 elementwise (BASELINE.json), 1e-12 * sum |term| for the float64 sum of the float32 data."""
+    from distributions_amd import beta, gamma, normal
+
+    rng = np.random.default_rng(44)
+    n = 1_234_567  # not a multiple of the tile: vector body + scalar tail
+    for m, name, params, x in ((normal, "normal", (0.3, 1.7), rng.normal(0, 1, n)), (gamma, "gamma", (2.5, 1.3), rng.gamma(2.5, 1 / 1.3, n)),
+                               (beta, "beta", (2.0, 5.0), rng.beta(2, 5, n))):
+        x32 = x.astype(np.float32)
+        x32[::100_003] = np.float32(-1.0) if name != "normal" else np.float32(np.inf)
+        exp = R.TABLE[f"{name}_logpdf"](x32.astype(np.float64), *params)
+        got = m.logpdf(x32, *[np.float32(p) if p != 1.3 and p != 1.7 and p != 0.3 else p for p in params])
+        assert got.dtype == np.float32
+        assert np.all(H.close(got.astype(np.float64), exp, 1e-5)), name
+        ok = x32 > 0 if name != "normal" else np.isfinite(x32)
+        terms = exp[ok]
+        tot = m.sum_logpdf(x32[ok], *params)
+        assert abs(tot - math.fsum(terms)) <= 1e-12 * float(np.abs(terms).sum()), name
+
+
 def test_sumlogp_product_form_edges(gpu):
     """The scalar-parameter sum-logp kernel carries sums of logarithms as products (Dist<>::SumAcc): zeros,
     subnormals, out-of-support points, inf and NaN must give what summing the elementwise results gives, and
