@@ -220,7 +220,7 @@ M355_DEV_HEAVY double gammaincc_cf(double a, double x, double lga) {
     const double pk = p1 * z - p2 * yc;
     const double qk = q1 * z - q2 * yc;
     const double pq = pk * q1;
-    const bool done = (qk != 0.0) & (q1 != 0.0) & (__builtin_fabs(p1 * qk - pq) <= kEps * __builtin_fabs(pq));
+    const bool done = (qk != 0.0) & (q1 != 0.0) & (__builtin_fabs(__builtin_fma(p1, qk, -pq)) <= kEps * __builtin_fabs(pq));
     p2 = p1;
     p1 = pk;
     q2 = q1;
@@ -421,7 +421,8 @@ M355_HD_HEAVY double betainc_pseries(double a, double b, double x, double lbeta)
 // Continued fraction DLMF 8.17.22, x < (a+1)/(a+b+2), by the forward recurrence of its numerators and
 // denominators A_k = b_k A_{k-1} + a_k A_{k-2} after the equivalence transformation that clears the partial
 // numerators' denominators (a_k' = D_{k-1} N_k, b_k' = D_k for a_k = N_k / D_k, b_k = 1): no division inside a step,
-// one per pair of steps for the convergence test, renormalised by a power of two after every pair.  Returns the fraction
+// the convergence test is cross-multiplied, the recurrence is rescaled by a power of two when it leaves [2^-100, 2^100],
+// one division at the end.  Returns the fraction
 // value (without the x^a(1-x)^b/(a B) prefactor).
 M355_HD_HEAVY double betainc_cf(double a, double b, double x) {
   const double qab = a + b, qam = a - 1.0;
@@ -429,7 +430,6 @@ M355_HD_HEAVY double betainc_cf(double a, double b, double x) {
   // evaluate f = 1 + d_1/(1 + d_2/(...)) and return 1 / f
   double Am = 1.0, Bm = 0.0, A = 1.0, B = 1.0;  // (A_{k-2}, B_{k-2}), (A_{k-1}, B_{k-1}) of f
   double Dprev = 1.0;
-  double ans = 1.0;
   for (int m = 1; m < kMaxIter; ++m) {
     M355_ITER();
     const double dm = (double)m, m2 = 2.0 * dm;
@@ -444,21 +444,17 @@ M355_HD_HEAVY double betainc_cf(double a, double b, double x) {
     Bn = D2 * B + t * Bm;
     Am = A; Bm = B; A = An; B = Bn;
     Dprev = D2;
-    // renormalise by the exact power of two that brings |A| + |B| to [1/2, 1): the D_k grow like (a + 2m)^2
+    // the D_k grow like (a + 2m)^2: rescale by an exact power of two when the pair leaves [2^-100, 2^100]
     const double mag = __builtin_fabs(A) + __builtin_fabs(B);
-    if (mag > 0.0 && mag < kInf) {
-      const int e = hw_frexp_exp(mag);
-      const double sc = __builtin_bit_cast(double, (unsigned long long)(1023 - e) << 52);
+    if (mag > 0x1p100 || mag < 0x1p-100) {
+      const double sc = mag > 1.0 ? 0x1p-100 : 0x1p100;
       A *= sc; B *= sc; Am *= sc; Bm *= sc;
     }
-    if (B != 0.0) {
-      const double r = fdiv(A, B);
-      const bool done = __builtin_fabs(ans - r) <= 2.0 * kEps * __builtin_fabs(r);
-      ans = r;
-      if (done) break;
-    }
+    // successive convergents Am/Bm and A/B agree to 2 eps: cross-multiplied, no quotient inside the loop
+    const double ab = A * Bm;
+    if ((B != 0.0) & (Bm != 0.0) & (__builtin_fabs(__builtin_fma(Am, B, -ab)) <= 2.0 * kEps * __builtin_fabs(ab))) break;
   }
-  return rcp(ans);
+  return fdiv(B, A);
 }
 
 // Regularised incomplete beta I_x(a,b) (pt.betainc).  `y` must be 1-x; lbeta = betaln(a,b).
