@@ -6,7 +6,7 @@
 #include <random>
 #include <vector>
 #include <algorithm>
-namespace m355 { long long g_m355_iters = 0; }
+namespace m355 { long long g_m355_iters = 0, g_m355_outer = 0; }
 #include "../distributions_amd/csrc/m355_dists.h"
 using namespace m355;
 template <int D, int FN> void run(const char* name, const std::vector<double>& xs, const double* p) {
@@ -14,6 +14,7 @@ template <int D, int FN> void run(const char* name, const std::vector<double>& x
   std::vector<long long> it;
   long long tot = 0;
   double worst = 0;
+  m355::g_m355_outer = 0;
   for (double x : xs) {
     m355::g_m355_iters = 0;
     volatile double r = Dist<D>::template eval<FN>(x, k);
@@ -25,8 +26,8 @@ template <int D, int FN> void run(const char* name, const std::vector<double>& x
   std::sort(s.begin(), s.end());
   size_t wi = std::max_element(it.begin(), it.end()) - it.begin();
   worst = xs[wi];
-  printf("%-18s mean %.1f  p50 %lld  p99 %lld  p99.99 %lld  max %lld (x=%.17g)\n", name, (double)tot / xs.size(), s[s.size() / 2],
-         s[s.size() * 99 / 100], s[(size_t)(s.size() * 0.9999)], s.back(), worst);
+  printf("%-18s mean %.1f  p50 %lld  p99 %lld  p99.99 %lld  max %lld (x=%.17g)  outer iterations/element %.2f\n", name, (double)tot / xs.size(),
+         s[s.size() / 2], s[s.size() * 99 / 100], s[(size_t)(s.size() * 0.9999)], s.back(), worst, (double)m355::g_m355_outer / xs.size());
 }
 int main() {
   const int n = 400000;
