@@ -298,6 +298,12 @@ M355_DEV double norm_quantile_guess(double p) {
 // makes the iterate bounce in the rounding noise of the forward function until the bracket is
 // exhausted: measured 6x the work at isolated q, tools/iter_probe.cpp.)
 constexpr double kRootStep = 2e-9;
+// A Halley step (third order) of relative size s leaves ~K s^3 with K = O(1) in the central region where it is used
+// (the tails take the Newton-on-log branches above): 2e-6 leaves ~1e-17 K and saves the evaluation that a 2e-9
+// threshold spends on confirming it (beta.ppf 3.1 -> 2.6 evaluations per quantile).  betaincinv_ only: in
+// gammaincinv_p the extra live value pushes the kernel from 168 to 178 VGPRs, i.e. from three wavefronts per SIMD to
+// two, which costs more (gamma.ppf 8.3 -> 9.8 ms) than the saved evaluation gains.
+constexpr double kRootStepHalley = 2e-6;
 
 // Inverse of P(a, .) (pt.gammaincinv): safeguarded Halley iteration on the smaller tail.
 M355_DEV_HEAVY double gammaincinv_p(double a, double p, double lga) {
@@ -335,6 +341,7 @@ M355_DEV_HEAVY double gammaincinv_p(double a, double p, double lga) {
   }
   double lo = 0.0, hi = kInf, shrink = 0.25, grow = 4.0;
   for (int it = 0; it < 200; ++it) {
+    M355_ITER_OUTER();
     double f, tail;  // f = P - p or q - Q: increasing in x either way
     if (upper) {
       tail = gammainc_q(a, x, lga);
@@ -580,6 +587,7 @@ M355_DEV_HEAVY double betaincinv_(double a, double b, double p, double lbeta, do
     if (f < 0.0) lo = t; else hi = t;
     const double d = exp_(log_beta_kernel(a, b, x, y, lbeta));  // x (1-x) |dI/dx|
     double tn = -1.0;
+    bool halley = false;
     if (d > 0.0 && d < kInf) {
       const double w = fdiv(d, x * y);  // |d tail / dt|
       if (target < 0.25 && tail > 0.0) {
@@ -590,10 +598,11 @@ M355_DEV_HEAVY double betaincinv_(double a, double b, double p, double lbeta, do
         double c2 = fdiv(a - 1.0, x) - fdiv(b - 1.0, y);  // I''/I' in x
         c2 = rep_y ? -c2 : c2;
         const double den = 1.0 - 0.5 * nstep * c2;
-        tn = t - ((den > 0.5 && den < 2.0) ? fdiv(nstep, den) : nstep);
+        halley = den > 0.5 && den < 2.0;
+        tn = t - (halley ? fdiv(nstep, den) : nstep);
       }
     }
-    if (tn > 0.0 && __builtin_fabs(tn - t) <= kRootStep * t) {  // converged (also when tn rounds onto a bracket end)
+    if (tn > 0.0 && __builtin_fabs(tn - t) <= (halley ? kRootStepHalley : kRootStep) * t) {  // converged (also when tn rounds onto a bracket end)
       t = tn;
       break;
     }
@@ -610,7 +619,7 @@ M355_DEV_HEAVY double betaincinv_(double a, double b, double p, double lbeta, do
     }
     const double dt = __builtin_fabs(tn - t);
     t = tn;
-    if (dt <= (safeguarded ? 4.0 * kEps : kRootStep) * t) break;  // as in gammaincinv_p
+    if (dt <= (safeguarded ? 4.0 * kEps : (halley ? kRootStepHalley : kRootStep)) * t) break;  // as in gammaincinv_p
   }
   return rep_y ? 1.0 - t : t;
 }
