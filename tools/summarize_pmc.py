@@ -21,7 +21,7 @@ out = {}
 for d in sorted(glob.glob(os.path.join(root, "gpurun_out", "pmc_*"))):
     if not os.path.isdir(d):
         continue
-    files = glob.glob(os.path.join(d, "*", "*_counter_collection.csv"))
+    files = sorted(glob.glob(os.path.join(d, "*", "*_counter_collection.csv")), key=os.path.getmtime, reverse=True)  # newest pass
     if not files:
         continue
     per = collections.defaultdict(lambda: collections.defaultdict(list))
