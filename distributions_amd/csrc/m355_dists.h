@@ -162,6 +162,7 @@ template <> struct Dist<M355_GAMMA> {
 
 // ----------------------------------------------------------------------------------------- beta
 template <> struct Dist<M355_BETA> {
+  static constexpr int kMinWaves = 3;  // binned kernel: 168-VGPR budget around the inlined betaincinv_ (m355_elemwise.h)
   static constexpr int kBinned = 1;  // logcdf / logsf / ppf ...: lanes diverge, see k_binned (m355_elemwise.h)
   static constexpr int NP = 2;
   static constexpr bool kLogTable = true;  // logpdf uses flog_tab
@@ -241,6 +242,7 @@ template <> struct Dist<M355_BETA> {
 
 // ------------------------------------------------------------------------------------- studentt
 template <> struct Dist<M355_STUDENTT> {
+  static constexpr int kMinWaves = 3;  // binned kernel: 168-VGPR budget around the inlined betaincinv_ (m355_elemwise.h)
   static constexpr int kBinned = 1;  // logcdf / logsf / ppf ...: lanes diverge, see k_binned (m355_elemwise.h)
   static constexpr int NP = 3;
   static constexpr bool kLogTable = true;  // logpdf uses flog1p_tab

@@ -748,6 +748,7 @@ template <> struct Dist<M355_SCALEDINVERSECHISQUARED> {
 
 // --------------------------------------------------------------------------------- halfstudentt
 template <> struct Dist<M355_HALFSTUDENTT> {
+  static constexpr int kMinWaves = 3;  // binned kernel: 168-VGPR budget around the inlined betaincinv_ (m355_elemwise.h)
   static constexpr int kBinned = 1;
   static constexpr int NP = 2;
   struct K { double nu, sigma, logsigma, c, lbeta_h, ihalf_h; };
@@ -794,6 +795,7 @@ template <> struct Dist<M355_HALFSTUDENTT> {
 
 // ----------------------------------------------------------------------------------- betascaled
 template <> struct Dist<M355_BETASCALED> {
+  static constexpr int kMinWaves = 3;  // binned kernel: 168-VGPR budget around the inlined betaincinv_ (m355_elemwise.h)
   static constexpr int kBinned = 1;
   static constexpr int NP = 4;
   static constexpr bool kLogTable = true;  // logpdf uses flog_tab

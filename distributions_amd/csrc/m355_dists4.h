@@ -226,6 +226,7 @@ template <> struct Dist<M355_TRUNCATEDNORMAL> {
 
 // -------------------------------------------------------------------------------- skew_studentt
 template <> struct Dist<M355_SKEW_STUDENTT> {
+  static constexpr int kMinWaves = 3;  // binned kernel: 168-VGPR budget around the inlined betaincinv_ (m355_elemwise.h)
   static constexpr int kBinned = 1;
   static constexpr int NP = 4;
   struct K { double a, b, mu, sigma, ab, sqab, lbeta, c, ihalf; };  // c = (a+b-1) log 2 + betaln + 0.5 log(a+b) + log sigma; ihalf = I_{1/2}(a, b)

@@ -293,8 +293,15 @@ constexpr int kBinPer = kBinTile / kBlock;
 constexpr int kBuckets = 256;
 constexpr int kBinMinTiles = 256;  // below ~5e5 elements the 1024-element tiles of k_scalar fill the 256 CUs better
 
+// Dist<D>::kMinWaves: register budget of the binned kernel in wavefronts per SIMD.  The betaincinv families inline the
+// root finder into the kernel (M355_DEV) so that this budget covers it: 168 VGPRs and a few spills instead of 194
+// VGPRs, i.e. three resident wavefronts instead of two -- beta.ppf 7.9 -> 6.1 ms at N = 1e8 (A/B on one box,
+// scripts/ab_tile.sh).  A budget cannot be given to a __noinline__ device function.
+template <class T, class = void> struct min_waves { static constexpr int value = 1; };
+template <class T> struct min_waves<T, std::void_t<decltype(T::kMinWaves)>> { static constexpr int value = T::kMinWaves; };
+
 template <int D, int FN>
-__global__ __launch_bounds__(kBlock) void k_binned(const void* __restrict__ x, int xdt, void* __restrict__ out,
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(min_waves<Dist<D>>::value))) void k_binned(const void* __restrict__ x, int xdt, void* __restrict__ out,
                                                    int odt, long long n, const typename Dist<D>::K k) {
   using DD = Dist<D>;
   __shared__ double xs[kBinTile];

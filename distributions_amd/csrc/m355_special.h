@@ -554,7 +554,9 @@ M355_DEV double betaincinv_guess(double a, double b, double p, double lbeta) {
 // Inverse of I_.(a,b) (pytensor.tensor.math.betaincinv).  The iterate t is x when the root is
 // <= 1/2 and y = 1-x otherwise (full relative accuracy of whichever is small).  Safeguarded Newton/Halley, with Newton on log(tail) while the tail is far below 1.
 // ihalf = betainc_half(a, b, lbeta) if the caller has it (NaN: evaluated here).
-M355_DEV_HEAVY double betaincinv_(double a, double b, double p, double lbeta, double ihalf = kNaN) {
+// Inlined into its callers (not __noinline__ like the other heavy functions): a register budget can only be given to a
+// kernel, and the binned quantile kernels give one (Dist<>::kMinWaves, m355_elemwise.h).
+M355_DEV double betaincinv_(double a, double b, double p, double lbeta, double ihalf = kNaN) {
   if (!(a > 0.0) || !(b > 0.0) || !(p >= 0.0) || !(p <= 1.0)) return kNaN;
   if (p == 0.0) return 0.0;
   if (p == 1.0) return 1.0;
