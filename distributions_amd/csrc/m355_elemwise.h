@@ -310,7 +310,9 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(min_wave
   __shared__ unsigned cnt[kBuckets];
   __shared__ unsigned long long red_min[kBlock / 64], red_max[kBlock / 64];
   __shared__ double red_s[kBlock / 64], red_c[kBlock / 64];
-  if constexpr (uses_log_table<DD>::value) log_table_init();
+  // kLogTable marks logpdf bodies (and pdf = exp(logpdf)): the other functions never touch the table, and without its
+  // 4 KiB the tile buffers fit four workgroups per CU instead of three (42128 -> 38032 bytes of LDS)
+  if constexpr (uses_log_table<DD>::value && (FN == M355_LOGPDF || FN == M355_PDF)) log_table_init();
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const long long ntiles = n / kBinTile;
   for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
