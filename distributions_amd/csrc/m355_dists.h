@@ -77,6 +77,7 @@ template <> struct Dist<M355_NORMAL> {
 
 // ---------------------------------------------------------------------------------------- gamma
 template <> struct Dist<M355_GAMMA> {
+  static constexpr int kMinWaves = 3;  // binned kernel: 168-VGPR budget around the inlined gammaincinv_p (m355_elemwise.h)
   static constexpr int kBinned = 1;  // logcdf / logsf / ppf ...: lanes diverge, see k_binned (m355_elemwise.h)
   static constexpr int NP = 2;
   static constexpr bool kLogTable = true;  // logpdf uses flog_tab

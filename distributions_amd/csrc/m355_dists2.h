@@ -596,6 +596,7 @@ template <> struct Dist<M355_LOGITNORMAL> {
 
 // --------------------------------------------------------------------------------- inversegamma
 template <> struct Dist<M355_INVERSEGAMMA> {
+  static constexpr int kMinWaves = 3;  // binned kernel: 168-VGPR budget around the inlined gammaincinv_p (m355_elemwise.h)
   static constexpr int kBinned = 1;
   static constexpr int NP = 2;
   struct K { double alpha, beta, lga, c; };
@@ -646,6 +647,7 @@ template <> struct Dist<M355_INVERSEGAMMA> {
 
 // ----------------------------------------------------------------------------------- chisquared
 template <> struct Dist<M355_CHISQUARED> {
+  static constexpr int kMinWaves = 3;  // binned kernel: 168-VGPR budget around the inlined gammaincinv_p (m355_elemwise.h)
   static constexpr int kBinned = 1;
   static constexpr int NP = 1;
   struct K { double nu, h, lgh, c; };  // h = nu/2
@@ -700,6 +702,7 @@ template <> struct Dist<M355_CHISQUARED> {
 
 // ---------------------------------------------------------------------- scaledinversechisquared
 template <> struct Dist<M355_SCALEDINVERSECHISQUARED> {
+  static constexpr int kMinWaves = 3;  // binned kernel: 168-VGPR budget around the inlined gammaincinv_p (m355_elemwise.h)
   static constexpr int kBinned = 1;
   static constexpr int NP = 2;
   struct K { double nu, tau2, h, ht, lgh, c; };  // h = nu/2, ht = h*tau2

@@ -300,13 +300,12 @@ M355_DEV double norm_quantile_guess(double p) {
 constexpr double kRootStep = 2e-9;
 // A Halley step (third order) of relative size s leaves ~K s^3 with K = O(1) in the central region where it is used
 // (the tails take the Newton-on-log branches above): 2e-6 leaves ~1e-17 K and saves the evaluation that a 2e-9
-// threshold spends on confirming it (beta.ppf 3.1 -> 2.6 evaluations per quantile).  betaincinv_ only: in
-// gammaincinv_p the extra live value pushes the kernel from 168 to 178 VGPRs, i.e. from three wavefronts per SIMD to
-// two, which costs more (gamma.ppf 8.3 -> 9.8 ms) than the saved evaluation gains.
+// threshold spends on confirming it (gamma.ppf 2.8 -> 2.5, beta.ppf 3.1 -> 2.6 evaluations per quantile).
 constexpr double kRootStepHalley = 2e-6;
 
 // Inverse of P(a, .) (pt.gammaincinv): safeguarded Halley iteration on the smaller tail.
-M355_DEV_HEAVY double gammaincinv_p(double a, double p, double lga) {
+// (inlined into its callers like betaincinv_: the binned quantile kernels give it a register budget)
+M355_DEV double gammaincinv_p(double a, double p, double lga) {
   if (!(a > 0.0) || !(p >= 0.0) || !(p <= 1.0)) return kNaN;
   if (p == 0.0) return 0.0;
   if (p == 1.0) return kInf;
@@ -354,6 +353,7 @@ M355_DEV_HEAVY double gammaincinv_p(double a, double p, double lga) {
     if (f < 0.0) lo = x; else hi = x;
     const double d = exp_(log_gamma_kernel(a, x, lga));  // x * |dP/dx|
     double xn = -1.0;
+    bool halley = false;
     if (d > 0.0 && d < kInf) {
       if (!upper && p < 0.25 && tail > 0.0) {
         // Newton on log P(log x): exact for the power-law tail P ~ x^a / Gamma(a+1)
@@ -365,10 +365,11 @@ M355_DEV_HEAVY double gammaincinv_p(double a, double p, double lga) {
         const double dx_rel = fdiv(f, d);                  // Newton step / x
         const double curv = 0.5 * dx_rel * (a - 1.0 - x);  // Halley: f''/f' = (a-1)/x - 1
         const double den = 1.0 - curv;
-        xn = x - x * ((den > 0.5 && den < 2.0) ? fdiv(dx_rel, den) : dx_rel);
+        halley = den > 0.5 && den < 2.0;
+        xn = x - x * (halley ? fdiv(dx_rel, den) : dx_rel);
       }
     }
-    if (xn > 0.0 && __builtin_fabs(xn - x) <= kRootStep * x) {  // converged (also when xn rounds onto a bracket end)
+    if (xn > 0.0 && __builtin_fabs(xn - x) <= (halley ? kRootStepHalley : kRootStep) * x) {  // converged (also when xn rounds onto a bracket end)
       x = xn;
       break;
     }
@@ -390,7 +391,7 @@ M355_DEV_HEAVY double gammaincinv_p(double a, double p, double lga) {
     x = xn;
     // a small Newton / Halley step squares (or cubes) the error it leaves: converged.  Safeguard
     // (bisection-like) steps only converge linearly and run down to a few ulp.
-    if (dx <= (safeguarded ? 4.0 * kEps : kRootStep) * x) break;
+    if (dx <= (safeguarded ? 4.0 * kEps : (halley ? kRootStepHalley : kRootStep)) * x) break;
   }
   return x;
 }
