@@ -20,7 +20,7 @@ os.makedirs(dst, exist_ok=True)
 
 
 def one(pattern):
-    hits = glob.glob(os.path.join(src, pattern))
+    hits = sorted(glob.glob(os.path.join(src, pattern)), key=os.path.getmtime, reverse=True)  # gpurun_out/ accumulates: newest pass
     return hits[0] if hits else None
 
 
