@@ -516,7 +516,17 @@ template <int D, int FN, bool REDUCE> int launch_fn(const LaunchArgs& a) {
   const long long cap = REDUCE ? kMaxReduceBlocks : kMaxBlocks;
   int blocks;
   if (vec_ok && (all_scalar || periodic_ok)) {
-    blocks = (int)(tiles < 1 ? 1 : (tiles > cap ? cap : tiles));
+    long long c = cap;
+    if (!all_scalar) {
+      // k_periodic: every workgroup derives the whole table (P x lgamma / log ...) before its first tile, so the grid
+      // is two rounds of what is resident (the table's LDS bounds that), not one workgroup per three tiles:
+      // at P = 1024 the 32768-block grid spent more on deriving tables than on evaluating elements
+      const size_t lds_b = (size_t)P * sizeof(typename DD::K) + 8192;
+      long long per_cu = (long long)(163840 / lds_b);
+      per_cu = per_cu < 1 ? 1 : (per_cu > 8 ? 8 : per_cu);
+      c = 2 * 256 * per_cu < c ? 2 * 256 * per_cu : c;
+    }
+    blocks = (int)(tiles < 1 ? 1 : (tiles > c ? c : tiles));
   } else {
     const long long want = (n + kBlock - 1) / kBlock;
     blocks = (int)(want < 1 ? 1 : (want > cap ? cap : want));
