@@ -237,6 +237,31 @@ def config9(torch, n):
                           "sets_per_s": float(f"{m / (ms * 1e-3):.4g}"), "integrand_evals_per_s": float(f"{m * evals / (ms * 1e-3):.4g}")}), flush=True)
 
 
+def config10(torch, n):
+    """Discrete families: logpdf, cdf and ppf on int64 observations drawn from each family's
+    own rvs kernel, scalar parameters.  logpdf is lgamma-bound, cdf runs gammaincc / betainc (or the reference's sum of
+    pmf for betabinomial / hypergeometric), ppf the in-kernel find_ppf_discrete."""
+    from distributions_amd import _dispatch, raw
+
+    cases = {"poisson": (100.0,), "binomial": (1000.0, 0.3), "negativebinomial": (10.0, 0.1), "geometric": (0.1,),
+             "betabinomial": (100.0, 20.0, 20.0), "hypergeometric": (50.0, 20.0, 10.0), "zi_poisson": (0.7, 10.0),
+             "discreteweibull": (0.9, 3.0)}
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev).manual_seed(10)
+    for name, p in cases.items():
+        x = _dispatch.rvs(name, p, size=n, random_state=5, as_torch=True)
+        q = torch.rand(n, dtype=torch.float64, device=dev, generator=g).clamp_(1e-6, 1 - 1e-6)
+        out = torch.empty(n, dtype=torch.float64, device=dev)
+        row = {"config": 10, "dist": name, "n": n}
+        for fn in ("logpdf", "cdf", "ppf"):
+            src = q if fn == "ppf" else x
+            ms = timed(torch, lambda: raw.elemwise_into(name, fn, src, p, out), reps=3, warmup=1)
+            row[f"{fn}_ms"] = round(ms, 4)
+            row[f"{fn}_evals_per_s"] = float(f"{n / (ms * 1e-3):.4g}")
+        print(json.dumps(row), flush=True)
+        del x, q, out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--config", default="all")
@@ -259,6 +284,8 @@ def main():
         config8(torch, args.n or 10_000_000)
     if args.config in ("9", "all"):
         config9(torch, args.n or 10_000_000)
+    if args.config in ("10", "all"):
+        config10(torch, args.n or 100_000_000)
 
 
 if __name__ == "__main__":

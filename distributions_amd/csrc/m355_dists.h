@@ -378,7 +378,7 @@ template <> struct Dist<M355_POISSON> {
   }
   // poisson.py:70-71: no support switch; gammaln's poles give -inf at negative integers (Q6).
   static M355_DEV double logpdf(double x, const K& k) {
-    return (xlogy0_l(x, k.logmu) - lgamma_(x + 1.0)) - k.mu;
+    return (xlogy0_l(x, k.logmu) - lgamma1p_obs(x)) - k.mu;
   }
   static M355_DEV double cdf(double x, const K& k) {  // poisson.py:49-50
     return cdf_bounds(gammainc_q(x + 1.0, k.mu, lgamma_(x + 1.0)), x, 0.0, kInf);
@@ -421,7 +421,7 @@ template <> struct Dist<M355_BINOMIAL> {
   }
   static M355_DEV double logpdf(double x, const K& k) {  // binomial.py:66-75
     const double nmx = k.n - x;
-    double r = k.lgn1 - lgamma_(x + 1.0) - lgamma_(nmx + 1.0) + xlogy0_l(x, k.logp) + nmx * k.log1mp;
+    double r = k.lgn1 - lgamma1p_obs(x) - lgamma1p_obs(nmx) + xlogy0_l(x, k.logp) + nmx * k.log1mp;
     return ((x < 0.0) | (x > k.n)) ? -kInf : r;
   }
   static M355_DEV double cdf(double x, const K& k) {  // binomial.py:45-46

@@ -5,6 +5,7 @@
 // All functions are per-lane scalar code: lanes of a wavefront that need different trip counts
 // simply run masked, there is no cross-lane communication.
 #pragma once
+#include "m355_logfact128.h"
 #include "m355_math.h"
 
 namespace m355 {
@@ -68,6 +69,31 @@ M355_DEV double atan_(double x) { return std::atan(x); }
 M355_DEV double tan_(double x) { return std::tan(x); }
 M355_DEV double pow_l(double x, double lx, double y) { (void)lx; return std::pow(x, y); }
 #endif
+
+// log Gamma(x + 1) for an observation x (poisson / binomial logpdf: gammaln(x + 1), gammaln(n - x + 1)).  Counts are
+// small integers or large: log(x!) from a 128-entry table for integer 0 <= x < 128 (correctly rounded values), Stirling's
+// series (DLMF 5.11.1 through z^-11: |error| < 2e-18 at z = x + 1 >= 16) with one logarithm and one reciprocal above,
+// the device libm's lgamma for everything else (non-integers below 15, negative arguments and their poles, inf, NaN).
+// ~30 fp64-op equivalents instead of ~90: poisson.logpdf goes from lgamma-bound to the HBM stream.
+M355_DEV double lgamma1p_obs(double x) {
+  constexpr double kLogFact[128] = {M355_LOGFACT128};
+  if ((x >= 0.0) & (x < 128.0)) {
+    const int i = (int)x;
+    if ((double)i == x) return kLogFact[i];
+  }
+  if ((x >= 15.0) & (x < 1e300)) {
+    const double z = x + 1.0;
+    const double w = rcp(z), w2 = w * w;
+    double p = -691.0 / 360360.0;
+    p = __builtin_fma(p, w2, 1.0 / 1188.0);
+    p = __builtin_fma(p, w2, -1.0 / 1680.0);
+    p = __builtin_fma(p, w2, 1.0 / 1260.0);
+    p = __builtin_fma(p, w2, -1.0 / 360.0);
+    p = __builtin_fma(p, w2, 1.0 / 12.0);
+    return (((z - 0.5) * flog_pos(z) - z) + kLogSqrt2Pi) + p * w;
+  }
+  return lgamma_(x + 1.0);
+}
 
 // pt.log1mexp: log(1 - exp(x)) for x <= 0.
 M355_DEV double log1mexp_(double x) {

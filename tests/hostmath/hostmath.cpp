@@ -180,4 +180,5 @@ extern "C" int hm_moment(int dist, int stat, long n, const double* p, double* ou
   return -1;
 }
 
+extern "C" void hm_lgamma1p_obs(long n, const double* x, double* out) { for (long i = 0; i < n; ++i) out[i] = lgamma1p_obs(x[i]); }
 extern "C" void hm_digamma(long n, const double* x, double* out) { for (long i = 0; i < n; ++i) out[i] = digamma_(x[i]); }

@@ -468,3 +468,17 @@ def test_host_moments_vs_oracle(hostlib, name, sp_dist, params, sp_params, suppo
         exp = float(M.moment(name, stat, *params))
         got = host_moment(hostlib, name, stat, params)
         assert H.moment_close(name, stat, got, exp, params), (name, stat, params, got, exp)
+
+
+def test_host_lgamma1p_obs(hostlib):
+    """lgamma1p_obs (csrc/m355_special.h: log Gamma(x + 1) for count observations -- table below 128, Stirling from 15)
+    against SciPy's gammaln: integers, the table / Stirling seams, non-integers, poles and non-finite arguments."""
+    rng = np.random.default_rng(61)
+    x = np.concatenate([np.arange(0, 400, dtype=np.float64), rng.uniform(0, 300, 5000), rng.uniform(14.9, 15.1, 200),
+                        np.floor(np.exp(rng.uniform(np.log(100), np.log(1e15), 5000))), np.exp(rng.uniform(np.log(15), np.log(1e300), 2000)),
+                        [127.0, 128.0, 127.5, 14.999999, 15.0, 1e300, 2e300, -0.5, -1.0, -2.0, -2.5, np.inf, np.nan]])
+    got = vec(hostlib, "hm_lgamma1p_obs", x)
+    with np.errstate(all="ignore"):
+        exp = sp.gammaln(x + 1.0)
+    ok = (got == exp) | (np.isnan(got) & np.isnan(exp)) | (np.abs(got - exp) <= 1e-15 * np.maximum(1.0, np.abs(exp)))
+    assert np.all(ok), (x[~ok][:5], got[~ok][:5], exp[~ok][:5])
