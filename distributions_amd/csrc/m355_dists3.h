@@ -115,7 +115,7 @@ M355_HD NegBinK negbin_derive(double n, double p) {
 }
 M355_DEV double negbin_logpdf(double x, const NegBinK& k) {
   if (x < 0.0) return -kInf;
-  return ((lgamma_(x + k.n) - lgamma_(x + 1.0)) + k.c) + xlogy0_l(x, k.log1mp);
+  return ((lgamma_obs(x + k.n) - lgamma1p_obs(x)) + k.c) + xlogy0_l(x, k.log1mp);
 }
 M355_DEV double negbin_cdf(double x, const NegBinK& k) {
   const double kk = floor_(x);
@@ -164,7 +164,7 @@ template <> struct Dist<M355_BETABINOMIAL> {
   }
   static M355_DEV double logpdf(double x, const K& k) {
     if ((x < 0.0) | (x > k.n)) return -kInf;
-    return (((k.c - lgamma_(x + 1.0)) - lgamma_(k.n - x + 1.0)) + lgamma_(x + k.a)) + lgamma_(k.n - x + k.b);
+    return (((k.c - lgamma1p_obs(x)) - lgamma_obs(k.n - x + 1.0)) + lgamma_obs(x + k.a)) + lgamma_obs(k.n - x + k.b);
   }
   static M355_DEV double cdf(double x, const K& k) {
     if (x < 0.0) return 0.0;
@@ -206,9 +206,9 @@ template <> struct Dist<M355_HYPERGEOMETRIC> {
   static M355_DEV double logpdf(double x, const K& k) {
     const double xf = floor_(x);
     if (!((xf >= k.lo) & (xf <= k.hi))) return -kInf;
-    const double a = (k.lgk1 - lgamma_(xf + 1.0)) - lgamma_(k.k - xf + 1.0);
+    const double a = (k.lgk1 - lgamma1p_obs(xf)) - lgamma_obs(k.k - xf + 1.0);
     const double nx = k.n - xf;
-    const double b = (k.lgNk1 - lgamma_(nx + 1.0)) - lgamma_((k.N - k.k) - nx + 1.0);
+    const double b = (k.lgNk1 - lgamma1p_obs(nx)) - lgamma_obs((k.N - k.k) - nx + 1.0);
     return (a + b) - k.lbNn;
   }
   static M355_DEV double cdf(double x, const K& k) {

@@ -75,14 +75,13 @@ M355_DEV double pow_l(double x, double lx, double y) { (void)lx; return std::pow
 // series (DLMF 5.11.1 through z^-11: |error| < 2e-18 at z = x + 1 >= 16) with one logarithm and one reciprocal above,
 // the device libm's lgamma for everything else (non-integers below 15, negative arguments and their poles, inf, NaN).
 // ~30 fp64-op equivalents instead of ~90: poisson.logpdf goes from lgamma-bound to the HBM stream.
-M355_DEV double lgamma1p_obs(double x) {
+M355_DEV double lgamma_obs(double z) {  // log Gamma(z), z = a count + 1 (or a count + a parameter)
   constexpr double kLogFact[128] = {M355_LOGFACT128};
-  if ((x >= 0.0) & (x < 128.0)) {
-    const int i = (int)x;
-    if ((double)i == x) return kLogFact[i];
+  if ((z >= 1.0) & (z < 129.0)) {
+    const int i = (int)z;
+    if ((double)i == z) return kLogFact[i - 1];
   }
-  if ((x >= 15.0) & (x < 1e300)) {
-    const double z = x + 1.0;
+  if ((z >= 16.0) & (z < 1e300)) {
     const double w = rcp(z), w2 = w * w;
     double p = -691.0 / 360360.0;
     p = __builtin_fma(p, w2, 1.0 / 1188.0);
@@ -92,8 +91,9 @@ M355_DEV double lgamma1p_obs(double x) {
     p = __builtin_fma(p, w2, 1.0 / 12.0);
     return (((z - 0.5) * flog_pos(z) - z) + kLogSqrt2Pi) + p * w;
   }
-  return lgamma_(x + 1.0);
+  return lgamma_(z);
 }
+M355_DEV double lgamma1p_obs(double x) { return lgamma_obs(x + 1.0); }
 
 // pt.log1mexp: log(1 - exp(x)) for x <= 0.
 M355_DEV double log1mexp_(double x) {
