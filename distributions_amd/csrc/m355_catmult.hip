@@ -170,7 +170,7 @@ template <int G> __global__ __launch_bounds__(kBlock) void k_multinomial(const M
     for (int j = l; j < a.k; j += G) {
       const double xv = load1(a.x, a.xdt, (unsigned long long)(row * a.k + j));
       const double pv = prow[j];
-      s_lg += lgamma_(xv + 1.0);
+      s_lg += lgamma1p_obs(xv);
       s_xlp = __builtin_fma(xv, ::log(pv > 1e-10 ? pv : 1e-10), s_xlp);
       s_x += xv;
       neg |= (xv < 0.0) ? 1 : 0;
@@ -184,7 +184,7 @@ template <int G> __global__ __launch_bounds__(kBlock) void k_multinomial(const M
     }
     if (l == 0) {
       const double nv = a.n_ptr ? a.n_ptr[row % a.n_mod] : a.n_scalar;
-      const double res = (lgamma_(nv + 1.0) - s_lg) + s_xlp;  // multinomial.py:43-44
+      const double res = (lgamma1p_obs(nv) - s_lg) + s_xlp;  // multinomial.py:43-44
       a.out[row] = (neg | (s_x != nv)) ? -kInf : res;        // multinomial.py:45-52
     }
   }
