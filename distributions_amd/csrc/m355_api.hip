@@ -3,6 +3,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <mutex>
 
 #include "m355_elemwise.h"
 #include "m355_error.h"
@@ -61,7 +62,12 @@ bool convert(const m355_operand& in, long long n, bool is_param, m355::DevOperan
   }
   out.div = (unsigned long long)in.div;
   out.mod = (unsigned long long)in.mod;
-  (void)n;
+  // i / div == 0 for every i < n: the operand is its element 0.  Normalised here so that the kernels' 32-bit index
+  // path (n < 2^32) never sees a divisor it would truncate.
+  if (n > 0 && in.div >= n) {
+    out.div = (unsigned long long)n;
+    out.mod = 1;
+  }
   return true;
 }
 
@@ -117,8 +123,9 @@ int check_launch(int rc) {
 extern "C" int m355_rvs_impl(int dist, int out_dtype, long long n, const m355::GenericOps* ops, unsigned long long seed,
                              unsigned stream_id, unsigned long long offset, void* out, hipStream_t s);
 
-extern "C" int m355_grad_impl(int dist, long long n, const m355::GenericOps* ops, void* dx, void* const* dparams,
-                              int out_dtype, double* sums, double* partials, hipStream_t stream);
+extern "C" int m355_grad_impl(int dist, long long n, const m355::GenericOps* ops, int nparams, void* dx,
+                              void* const* dparams, int out_dtype, double* sums, double* partials,
+                              hipStream_t stream);
 
 extern "C" {
 
@@ -149,7 +156,10 @@ int m355_elemwise(int dist, int fn, int out_dtype, int64_t n, const m355_operand
   return check_launch(dispatch(dist, a));
 }
 
+// What callers are told to bring (kMaxBlocks doubles: kept from the first release so that existing workspaces stay
+// valid); what the kernels can touch is kMaxReduceBlocks partials (launch_fn caps every REDUCE grid there).
 size_t m355_sumlogp_workspace_bytes(void) { return (size_t)m355::kMaxBlocks * sizeof(double); }
+static size_t sumlogp_workspace_min_bytes() { return (size_t)m355::kMaxReduceBlocks * sizeof(double); }
 
 int m355_sumlogp(int dist, int fn, int64_t n, const m355_operand* x, int nparams,
                  const m355_operand* params, double* out_sum, void* workspace, size_t workspace_bytes,
@@ -160,7 +170,7 @@ int m355_sumlogp(int dist, int fn, int64_t n, const m355_operand* x, int nparams
   if (fn != M355_LOGPDF && fn != M355_LOGCDF && fn != M355_LOGSF)
     return fail(M355_ERR_UNSUPPORTED, "sum-logp is defined for logpdf/logcdf/logsf only");
   if (out_sum == nullptr || workspace == nullptr) return fail(M355_ERR_INVALID, "out_sum and workspace must not be NULL");
-  if (workspace_bytes < m355_sumlogp_workspace_bytes())
+  if (workspace_bytes < sumlogp_workspace_min_bytes())
     return fail(M355_ERR_WORKSPACE, "workspace of %zu bytes is smaller than the required %zu", workspace_bytes,
                 m355_sumlogp_workspace_bytes());
   hipStream_t s = static_cast<hipStream_t>(stream);
@@ -199,7 +209,7 @@ int m355_logpdf_grad(int dist, int out_dtype, int64_t n, const m355_operand* x, 
   m355::GenericOps ops;
   ops.x = a.x;
   for (int q = 0; q < m355::kMaxParams; ++q) ops.p[q] = a.p[q];
-  return check_launch(m355_grad_impl(dist, n, &ops, dx, dparams, out_dtype, sums, static_cast<double*>(workspace), s));
+  return check_launch(m355_grad_impl(dist, n, &ops, nparams, dx, dparams, out_dtype, sums, static_cast<double*>(workspace), s));
 }
 
 int m355_rvs(int dist, int out_dtype, int64_t n, int nparams, const m355_operand* params, uint64_t seed,

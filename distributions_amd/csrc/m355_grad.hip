@@ -228,14 +228,16 @@ template <int D> int launch_grad(const GradArgs& a) {
 }  // namespace m355
 
 // Called by m355_logpdf_grad (m355_api.hip) after argument validation.
-extern "C" int m355_grad_impl(int dist, long long n, const m355::GenericOps* ops, void* dx, void* const* dparams,
-                              int out_dtype, double* sums, double* partials, hipStream_t stream) {
+extern "C" int m355_grad_impl(int dist, long long n, const m355::GenericOps* ops, int nparams, void* dx,
+                              void* const* dparams, int out_dtype, double* sums, double* partials,
+                              hipStream_t stream) {
   m355::GradArgs a;
   a.n = n;
   a.x = ops->x;
   for (int q = 0; q < m355::kMaxParams; ++q) {
     a.p[q] = ops->p[q];
-    a.out.dparam[q] = dparams ? dparams[q] : nullptr;
+    // dparams is a host array of exactly nparams entries (include/m355_dist.h): never read past it
+    a.out.dparam[q] = (dparams && q < nparams) ? dparams[q] : nullptr;
   }
   a.out.dx = dx;
   a.out.dtype = out_dtype;

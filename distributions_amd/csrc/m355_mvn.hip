@@ -474,7 +474,10 @@ template <int NB, bool MU_ROWS> int launch_mfma(const m355::MfmaArgs& a, hipStre
   const long long ntiles = (a.n + 15) / 16;
   long long blocks = (ntiles + m355::kMfmaWaves - 1) / m355::kMfmaWaves;
   long long cap = 2 * 256;  // two workgroups per CU: every wavefront sees >= 2 tiles and prefetches
-  if (const char* e = getenv("M355_MVN_BLOCKS")) cap = atoll(e);
+  if (const char* e = getenv("M355_MVN_BLOCKS")) {  // A/B knob for grid sweeps; ignored unless a positive count
+    const long long v = atoll(e);
+    if (v >= 1) cap = v;
+  }
   if (blocks > cap) blocks = cap;
   hipLaunchKernelGGL((m355::k_solve_mfma<NB, MU_ROWS>), dim3((unsigned)blocks), dim3(64 * m355::kMfmaWaves), lds, s, a);
   return launched();

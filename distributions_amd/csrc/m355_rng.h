@@ -43,10 +43,12 @@ M355_HD Philox philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3,
   return p;
 }
 
-// 53-bit uniform in the open interval (0, 1) from two 32-bit words.
+// Uniform in the open interval (0, 1) from two 32-bit words: 52 random bits k, u = (k + 1/2) 2^-52.  k + 1/2 needs
+// 53 significant bits, so it is exact and u lies in [2^-53, 1 - 2^-53] (with 53 random bits k + 1/2 would round to
+// 2^53 for the largest k and u would be exactly 1: log(1 - u) = -inf in the inverse-CDF samplers).
 M355_HD double u53(unsigned hi, unsigned lo) {
-  const unsigned long long k = ((unsigned long long)(hi >> 5) << 26) | (unsigned long long)(lo >> 6);
-  return ((double)k + 0.5) * 0x1.0p-53;
+  const unsigned long long k = ((unsigned long long)(hi >> 6) << 26) | (unsigned long long)(lo >> 6);
+  return ((double)k + 0.5) * 0x1.0p-52;
 }
 
 // Stream of uniform pairs for one element: pair j is Philox block (index, attempt = j, stream).
