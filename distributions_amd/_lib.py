@@ -113,6 +113,9 @@ def lib():
     L.m355_sumlogp_workspace_bytes.restype = sz
     L.m355_sumlogp.restype = i32
     L.m355_sumlogp.argtypes = [i32, i32, i64, op, i32, op, vp, vp, sz, vp]
+    L.m355_sumlogp_static_max_n.restype = i64
+    L.m355_sumlogp_static.restype = i32
+    L.m355_sumlogp_static.argtypes = [i32, i32, i64, op, i32, op, vp, vp]
     L.m355_rvs.restype = i32
     L.m355_rvs.argtypes = [i32, i32, i64, i32, op, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint64, vp, vp]
     L.m355_grad_supported.restype = i32

@@ -190,6 +190,52 @@ int m355_sumlogp(int dist, int fn, int64_t n, const m355_operand* x, int nparams
   return check_launch((int)hipGetLastError());
 }
 
+// ---- m355_sumlogp_static: the sum-logp path for callers that cannot allocate (include/m355_dist.h) ----------------
+// The per-workgroup partials live in this file-scope device array instead of a caller workspace.  `scratch` names the
+// array for device code only: host code uses the per-device address obtained once from hipGetSymbolAddress.
+}  // extern "C"
+namespace {
+constexpr int kStaticPartials = m355::kMaxReduceBlocks;  // 4096 doubles = 32 KiB per GPU, held until process exit
+static __device__ __align__(256) double scratch[kStaticPartials];
+constexpr int kMaxDevices = 64;
+std::mutex g_scratch_mu;
+double* g_scratch_ptr[kMaxDevices] = {};
+
+// Address of `scratch` on the current device (looked up once per device, with that device current).
+int static_scratch(double** out) {
+  int dev = -1;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return fail(M355_ERR_LAUNCH, "hipGetDevice: %s", hipGetErrorString(e));
+  if (dev < 0 || dev >= kMaxDevices) return fail(M355_ERR_INVALID, "device ordinal %d beyond the %d supported", dev, kMaxDevices);
+  std::lock_guard<std::mutex> lock(g_scratch_mu);
+  if (g_scratch_ptr[dev] == nullptr) {
+    double* p = nullptr;
+    e = hipGetSymbolAddress(reinterpret_cast<void**>(&p), HIP_SYMBOL(scratch));
+    if (e != hipSuccess || p == nullptr)
+      return fail(M355_ERR_LAUNCH, "hipGetSymbolAddress(scratch) on device %d: %s", dev, hipGetErrorString(e));
+    g_scratch_ptr[dev] = p;
+  }
+  *out = g_scratch_ptr[dev];
+  return M355_OK;
+}
+}  // namespace
+extern "C" {
+
+int64_t m355_sumlogp_static_max_n(void) { return M355_SUMLOGP_STATIC_MAX_N; }
+
+int m355_sumlogp_static(int dist, int fn, int64_t n, const m355_operand* x, int nparams, const m355_operand* params,
+                        double* out_sum, void* stream) {
+  if (n > M355_SUMLOGP_STATIC_MAX_N)
+    return fail(M355_ERR_WORKSPACE, "m355_sumlogp_static: n = %lld exceeds the maximum of %lld elements per call",
+                (long long)n, (long long)M355_SUMLOGP_STATIC_MAX_N);
+  double* ws = nullptr;
+  const int rc = static_scratch(&ws);
+  if (rc != M355_OK) return rc;
+  // same kernels, same grid and same fixed-order final pass as m355_sumlogp: the totals are bit-identical.  Every
+  // launch writes partials [0, nblocks) before k_final reads exactly those, so nothing has to start at zero.
+  return m355_sumlogp(dist, fn, n, x, nparams, params, out_sum, ws, sizeof(double) * kStaticPartials, stream);
+}
+
 int m355_logpdf_grad(int dist, int out_dtype, int64_t n, const m355_operand* x, int nparams,
                      const m355_operand* params, double* sums, void* dx, void* const* dparams, void* workspace,
                      size_t workspace_bytes, void* stream) {

@@ -33,8 +33,9 @@ def elemwise_into(dist: str, fn: str, x, params, out) -> None:
     assert out.numel() == x.numel() and out.dtype in (torch.float64, torch.float32)
     ops = _operands(x, params, torch)
     stream = torch.cuda.current_stream(x.device).cuda_stream
-    _lib.check(_lib.lib().m355_elemwise(DIST[dist], FN[fn], _dt(out, torch), x.numel(), _p(ops, 0),
-                                        len(params), _p(ops, 1), out.data_ptr(), stream))
+    with torch.cuda.device(x.device):  # the launch goes to HIP's current device: make it x's
+        _lib.check(_lib.lib().m355_elemwise(DIST[dist], FN[fn], _dt(out, torch), x.numel(), _p(ops, 0),
+                                            len(params), _p(ops, 1), out.data_ptr(), stream))
 
 
 def sumlogp_workspace(device):
@@ -50,8 +51,22 @@ def sumlogp_into(dist: str, fn: str, x, params, out_sum, workspace) -> None:
     assert x.is_cuda and x.is_contiguous() and out_sum.dtype == torch.float64 and out_sum.is_cuda
     ops = _operands(x, params, torch)
     stream = torch.cuda.current_stream(x.device).cuda_stream
-    _lib.check(_lib.lib().m355_sumlogp(DIST[dist], FN[fn], x.numel(), _p(ops, 0), len(params), _p(ops, 1),
-                                       out_sum.data_ptr(), workspace.data_ptr(), workspace.numel(), stream))
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.lib().m355_sumlogp(DIST[dist], FN[fn], x.numel(), _p(ops, 0), len(params), _p(ops, 1),
+                                           out_sum.data_ptr(), workspace.data_ptr(), workspace.numel(), stream))
+
+
+def sumlogp_static_into(dist: str, fn: str, x, params, out_sum) -> None:
+    """sumlogp_into through m355_sumlogp_static: no workspace, nothing allocated (partials in the library's static
+    device array; calls that overlap on one GPU race on it -- include/m355_dist.h)."""
+    import torch
+
+    assert x.is_cuda and x.is_contiguous() and out_sum.dtype == torch.float64 and out_sum.is_cuda
+    ops = _operands(x, params, torch)
+    stream = torch.cuda.current_stream(x.device).cuda_stream
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.lib().m355_sumlogp_static(DIST[dist], FN[fn], x.numel(), _p(ops, 0), len(params), _p(ops, 1),
+                                                  out_sum.data_ptr(), stream))
 
 
 def logpdf_grad_into(dist: str, x, params, sums, dx, workspace) -> None:
@@ -63,7 +78,8 @@ def logpdf_grad_into(dist: str, x, params, sums, dx, workspace) -> None:
     assert dx is None or (dx.is_cuda and dx.is_contiguous() and dx.numel() == x.numel())
     ops = _operands(x, params, torch)
     stream = torch.cuda.current_stream(x.device).cuda_stream
-    _lib.check(_lib.lib().m355_logpdf_grad(DIST[dist], _dt(dx, torch) if dx is not None else F64, x.numel(), _p(ops, 0),
-                                           len(params), _p(ops, 1), sums.data_ptr(),
-                                           dx.data_ptr() if dx is not None else None, None, workspace.data_ptr(),
-                                           workspace.numel(), stream))
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.lib().m355_logpdf_grad(DIST[dist], _dt(dx, torch) if dx is not None else F64, x.numel(),
+                                               _p(ops, 0), len(params), _p(ops, 1), sums.data_ptr(),
+                                               dx.data_ptr() if dx is not None else None, None, workspace.data_ptr(),
+                                               workspace.numel(), stream))

@@ -152,6 +152,25 @@ int m355_sumlogp(int dist, int fn, int64_t n, const m355_operand* x, int nparams
                  size_t workspace_bytes, void* stream);
 
 /*
+ * m355_sumlogp without a workspace argument and without any allocation.  NO COUNTERPART IN THE REFERENCE: it exists
+ * for callers that cannot allocate device memory around the call -- code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc.  The per-workgroup partials live in a file-scope `static __device__`
+ * array of the library (4096 doubles = 32 KiB on every GPU the library runs on, held until the process ends); its
+ * per-device address is looked up once (hipGetSymbolAddress, first call on that device, device current).  Same
+ * kernels, grid and fixed-order final pass as m355_sumlogp, so *out_sum is bit-identical to it.  The call itself
+ * performs no hipMalloc / hipFree and never synchronises.
+ *   - n above M355_SUMLOGP_STATIC_MAX_N is rejected with M355_ERR_WORKSPACE (use m355_sumlogp, or split the range
+ *     and add the totals).
+ *   - every call on one GPU shares that GPU's array: calls that overlap in time on one GPU (different streams or
+ *     host threads) race on it -- serialise them, or give concurrent callers m355_sumlogp with a workspace each.
+ *     Nothing has to start at zero: each call overwrites the partials it later reads.
+ */
+#define M355_SUMLOGP_STATIC_MAX_N (INT64_C(1) << 32) /* elements per call (32 GiB of float64) */
+int64_t m355_sumlogp_static_max_n(void);
+int m355_sumlogp_static(int dist, int fn, int64_t n, const m355_operand* x, int nparams,
+                        const m355_operand* params, double* out_sum, void* stream);
+
+/*
  * Value and gradient of the summed log-likelihood in one pass.  The reference has no
  * function for this: its logpdf graphs (e.g. normal.py:79-80, gamma.py:77-82, beta.py:102-108,
  * studentt.py:108-119 and the closed-form families) are differentiated by pytensor.grad; this entry point
