@@ -31,15 +31,10 @@ def config2(torch, n):
     from bench import make_inputs
 
     dev = torch.device("cuda", 0)
-    xs = make_inputs(torch, n, dev, seed=2)
-    g = torch.Generator(device=dev).manual_seed(4)
-    z = torch.randn(n, dtype=torch.float64, device=dev, generator=g)
-    c = torch.zeros(n, dtype=torch.float64, device=dev)
-    for _ in range(5):
-        c += torch.randn(n, dtype=torch.float64, device=dev, generator=g) ** 2
-    xs["studentt"] = 2.0 * z / torch.sqrt(c / 5.0)
-    del z, c
-    q = torch.rand(n, dtype=torch.float64, device=dev, generator=g).clamp_(1e-12, 1 - 1e-12)
+    xs = make_inputs(torch, n, dev)  # SURVEY.md 8(d) config-2 inputs, Philox seeds 1-4 (normal, gamma, beta, studentt)
+    q = torch.empty(n, dtype=torch.float64, device=dev)
+    raw.rvs_into("uniform", (0.0, 1.0), q, seed=5)
+    q.clamp_(1e-12, 1 - 1e-12)
     out = torch.empty(n, dtype=torch.float64, device=dev)
     params = {"normal": (0.3, 1.7), "gamma": (2.5, 1.3), "beta": (2.0, 5.0), "studentt": (5.0, 0.0, 2.0)}
     for name, p in params.items():

@@ -83,3 +83,19 @@ def logpdf_grad_into(dist: str, x, params, sums, dx, workspace) -> None:
                                                _p(ops, 0), len(params), _p(ops, 1), sums.data_ptr(),
                                                dx.data_ptr() if dx is not None else None, None, workspace.data_ptr(),
                                                workspace.numel(), stream))
+
+
+def rvs_into(dist: str, params, out, seed: int, stream_id: int = 0, counter_offset: int = 0) -> None:
+    """Fill the contiguous CUDA tensor `out` (float64 / float32, or int64 for the discrete families) with draws of
+    `dist` with scalar parameters: Philox counter = counter_offset + i, so a range split over calls or GPUs gives
+    the same values as one call."""
+    import torch
+
+    assert out.is_cuda and out.is_contiguous()
+    ops = (Operand * max(len(params), 1))()
+    for j, p in enumerate(params):
+        ops[j].ptr, ops[j].scalar, ops[j].div, ops[j].mod, ops[j].dtype = None, float(p), 1, 1, F64
+    stream = torch.cuda.current_stream(out.device).cuda_stream
+    with torch.cuda.device(out.device):
+        _lib.check(_lib.lib().m355_rvs(DIST[dist], _dt(out, torch), out.numel(), len(params), _p(ops, 0), int(seed),
+                                       int(stream_id), int(counter_offset), out.data_ptr(), stream))
