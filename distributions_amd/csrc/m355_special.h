@@ -425,8 +425,13 @@ M355_DEV double gammaincinv_p(double a, double p, double lga) {
 // ------------------------------------------------------------------------------------------------
 // log( x^a (1-x)^b / B(a,b) ) with y = 1 - x supplied separately (so that callers that know 1-x
 // exactly keep it).  lbeta = lgamma(a)+lgamma(b)-lgamma(a+b).
+// Of x and y the smaller one is the accurate one (the callers hold it exactly; the other is 1 - it, rounded), so the
+// logarithm of the larger is taken as log1p(-smaller): with log(1 - x) from the rounded 1 - x the term b log y carries
+// b * 1.1e-16 of absolute error (5.5e-11 at b = 5e5: measured on betainc(1/2, nu/2, .) at nu = 1e6).
 M355_HD double log_beta_kernel(double a, double b, double x, double y, double lbeta) {
-  return a * flog(x) + b * flog(y) - lbeta;
+  const double lx = (y < 0.5) ? flog1p(-y) : flog(x);
+  const double ly = (x < 0.5) ? flog1p(-x) : flog(y);
+  return a * lx + b * ly - lbeta;
 }
 
 // Power series for I_x(a,b), good when b*x <= 1 and x <= 0.95 (DLMF 8.17.8 rearranged):

@@ -324,7 +324,61 @@ def family_ok(name, fn, got, exp, params=None):
             if fn in ("cdf", "sf"):
                 return np.abs(got - exp) <= HALFSTUDENTT_PROB_TOL
             return np.abs(np.exp(got) - np.exp(exp)) <= HALFSTUDENTT_PROB_TOL
-    return cancellation_ok(fn, got, exp)
+    if fn in CANCELLATION_FNS.get(name, ()):
+        return cancellation_ok(fn, got, exp)
+    return np.zeros(np.shape(got), dtype=bool)
+
+
+# (family, function) pairs whose REFERENCE formula is the log of a difference of O(1) quantities; only these take the
+# probability-scale comparison of cancellation_ok (it accepts any two values once both probabilities are below 2e-13,
+# so it must not be applied where the reference's log value is meaningful in the deep tail).
+CANCELLATION_FNS = {
+    # logsf = log1p(-cdf) / log(1 - cdf) / log(sf) with sf = 1 - cdf
+    "binomial": ("logsf",),          # binomial.py:82-83
+    "bernoulli": ("logsf",),         # bernoulli.py:74-75
+    "geometric": ("logsf",),         # geometric.py:75-76
+    "discreteuniform": ("logsf",),   # discreteuniform.py:77-78
+    "hypergeometric": ("logsf",),    # hypergeometric.py:101-102
+    "betabinomial": ("logsf",),      # betabinomial.py:103-104, 119-120
+    "zi_binomial": ("logsf",),       # zi_binomial.py:128-129
+    "polyagamma": ("logsf",),        # polyagamma.py:146-147
+    "vonmises": ("logsf",),          # vonmises.py:68-69
+    "exgaussian": ("logsf",),        # exgaussian.py:115-116: log1p(-exp(logcdf))
+    "lognormal": ("logsf",),         # lognormal.py:102: log1p(-0.5 (1 + erf))
+    "logitnormal": ("logsf",),       # logitnormal.py:175
+    "gumbel": ("logsf",),            # gumbel.py:80: log1p(-exp(-exp(-z)))
+    # logcdf = log(1 - something of O(1))
+    "pareto": ("logcdf",),           # pareto.py:74: log(1 - (m/x)^alpha)
+    "moyal": ("logcdf",),            # moyal.py:72: log(1 - erf(.))
+    "kumaraswamy": ("logcdf",),      # kumaraswamy.py:93: log(1 - (1 - x^a)^b)
+}
+
+
+# Quantiles are held to 1e-12 like everything else.  The one measured exception: studentt / halfstudentt pass
+# x = betaincinv(nu/2, 1/2, .) = 1 - delta, delta = t^2 / (nu + t^2), through sqrt(nu) sqrt(1/x - 1) (studentt.py:85-86,
+# halfstudentt.py ppf).  In the reference itself one ulp of x (1.1e-16) moves the quantile t by 1.1e-16 / (2 delta)
+# relative, which exceeds 1e-12 once nu / t^2 > ~2e4; and our betainc's continued fraction at x -> 1 carries ~1e-16 a
+# of relative noise (a = nu/2; measured against mpmath / SciPy roots at nu = 1e4, 1e5, 1e6: 5e-13, 5e-12, 5e-11).
+# The allowance is exactly that model -- 4 ulp of x through the amplification plus 2e-16 nu -- and vanishes for the
+# parameters the reference tests and BASELINE.json's configs use (nu <= 100: < 2e-14).
+def _student_window(params, exp, halfstudentt):
+    nu = float(params[0])
+    mu, sigma = (0.0, float(params[1])) if halfstudentt else (float(params[1]), float(params[2]))
+    with np.errstate(all="ignore"):
+        t = np.abs((np.asarray(exp, dtype=np.float64) - mu) / sigma)
+        delta = t * t / (nu + t * t)
+        amp = np.where(delta > 0, 4 * 1.1e-16 / (2 * delta), 0.0) + 2e-16 * nu
+        return np.where(np.isfinite(t), amp * t * sigma, 0.0)  # absolute allowance on the quantile
+
+
+def ppf_close(name, fn, params, got, exp):
+    """close() at 1e-12 plus, for quantiles of studentt / halfstudentt, the modelled allowance above."""
+    ok = close(got, exp, 1e-12)
+    if fn in ("ppf", "isf") and name in ("studentt", "halfstudentt") and params is not None and np.ndim(params[0]) == 0:
+        with np.errstate(all="ignore"):
+            extra = _student_window(params, exp, name == "halfstudentt")
+            ok |= np.abs(np.asarray(got) - np.asarray(exp)) <= 1e-12 * np.maximum(1.0, np.abs(exp)) + extra
+    return ok
 
 
 def ppf_unpinned(name, fn, pts):

@@ -227,10 +227,9 @@ def test_host_bodies_vs_oracle_1e12(hostlib, name, sp_dist, params, sp_params, s
         ok = _close(got, exp) | H.family_ok(name, fn, got, exp, params) | H.ppf_unpinned(name, fn, pts)
         if fn in ("ppf", "isf") and name in ("beta", "studentt", "halfstudentt", "betascaled", "skew_studentt"):
             # the oracle's betaincinv (SciPy) returns NaN / clamps for extreme tails (SURVEY App. C,
-            # "version-dependent, unpinned"); studentt.ppf amplifies 1 ulp of betaincinv near the
-            # median through 1/x - 1 (reference formula, studentt.py:85-86)
-            with np.errstate(all="ignore"):
-                ok |= np.isnan(exp) | (np.abs(got - exp) <= 1e-9 * np.maximum(1.0, np.abs(exp)))
+            # "version-dependent, unpinned"); studentt / halfstudentt amplify 1 ulp of betaincinv through 1/x - 1
+            # (reference formula, studentt.py:85-86): modelled allowance in harness.ppf_close, 1e-12 otherwise
+            ok |= np.isnan(exp) | H.ppf_close(name, fn, params, got, exp)
             ok |= (pts < 1e-100) | (pts > 1 - 1e-15)
         assert np.all(ok), (name, fn, params, pts[~ok][:5], got[~ok][:5], exp[~ok][:5])
 
@@ -258,7 +257,7 @@ def test_host_discrete_vs_oracle(hostlib, name, params, support):
         if fn in ("ppf", "isf"):
             ok = (got == exp) | (np.isnan(got) & np.isnan(exp))
         else:
-            ok = _close(got, exp) | H.cancellation_ok(fn, got, exp)
+            ok = _close(got, exp) | H.family_ok(name, fn, got, exp, params)
         assert np.all(ok), (name, fn, params, pts[~ok][:5], got[~ok][:5], exp[~ok][:5])
 
 
@@ -315,7 +314,7 @@ def test_host_polyagamma_vs_oracle(hostlib, h, z):
         with np.errstate(all="ignore"):
             exp = R.TABLE[f"polyagamma_{fn}"](xs, h, z)
         got = getattr(ns, fn)(xs, h, z)
-        ok = _close(got, exp) | H.cancellation_ok(fn, got, exp)
+        ok = _close(got, exp) | H.family_ok("polyagamma", fn, got, exp)
         assert np.all(ok), (fn, h, z, xs[~ok][:5], got[~ok][:5], exp[~ok][:5])
 
 
