@@ -30,12 +30,30 @@ M355_DEV double sf_bounds(double v, double q, double lower, double upper) {
 }
 
 // --------------------------------------------------------------------------------------- normal
-// normal.logcdf body on a standardised z (normal.py:70-76).
+// normal.logcdf body on a standardised z (normal.py:70-76):
+//   z < -1: log(erfcx(-z/sqrt2)/2) - z^2/2,   else: log1p(-erfc(z/sqrt2)/2).
+// One evaluation of w = erfcx(|z|/sqrt2) serves every z, without a branch: for z < 0 (both reference arms: on
+// -1 <= z < 0 the second arm is log1p(-(2 - erfc(|z|/sqrt2))/2) = log(w/2) - z^2/2, the same number to rounding)
+// the result is log(w/2) - z^2/2; for z >= 0 it is log1p(u), u = -w exp(-z^2/2)/2, taken as log(1 + u) plus the
+// rounding of 1 + u -- so a single logarithm, of a per-lane selected argument, covers both signs.
 M355_DEV double normal_logcdf_z(double z) {
-  if (z < -1.0) {
-    return flog(0.5 * erfcx_(-z * kInvSqrt2)) - 0.5 * z * z;
-  }
-  return flog1p(-0.5 * erfc_(z * kInvSqrt2));
+  const double h = 0.5 * z * z;
+  const double w = erfcx_pos(__builtin_fabs(z) * kInvSqrt2);
+  const bool neg = z < 0.0;
+  const double u = -0.5 * w * exp_(-h);
+  const double f1 = 1.0 + u;
+  const double f = neg ? 0.5 * w : f1;
+  double c = neg ? 0.0 : u - (f1 - 1.0);
+  c = ((f > 0.0) & (f < kInf)) ? c * hw_rcp(f) : 0.0;
+  const double l = flog_fast_t<1, true>(f) + c;  // one Newton step + residual correction: the quotient is exact to 2^-96
+  return neg ? l - h : l;
+}
+// (x - mu) / sigma as the reference divides, from the host's correctly rounded 1/sigma: product plus one residual
+// correction (<= 1 ulp from the IEEE quotient, three operations instead of the ~14 of v_div_scale / fmas / fixup).
+M355_DEV double standardise(double d, double sigma, double inv_sigma) {
+  const double q = d * inv_sigma;
+  const double v = __builtin_fma(__builtin_fma(-q, sigma, d), inv_sigma, q);
+  return (q - q == 0.0) ? v : q;  // inf / NaN quotients pass through (the residual would be inf - inf)
 }
 
 template <> struct Dist<M355_NORMAL> {
@@ -59,9 +77,9 @@ template <> struct Dist<M355_NORMAL> {
       const double z = (x - k.mu) / k.sigma;
       return 1.0 / sqrt_(2.0 * kPi * k.sigma * k.sigma) * exp_(-0.5 * z * z);
     } else if constexpr (FN == M355_LOGCDF) {  // normal.py:70-76
-      return normal_logcdf_z((x - k.mu) / k.sigma);
+      return normal_logcdf_z(standardise(x - k.mu, k.sigma, k.inv_sigma));
     } else if constexpr (FN == M355_LOGSF) {  // normal.py:83-84: logcdf(-x, -mu, sigma)
-      return normal_logcdf_z((-x + k.mu) / k.sigma);
+      return normal_logcdf_z(standardise(-x + k.mu, k.sigma, k.inv_sigma));
     } else if constexpr (FN == M355_SF) {  // normal.py:62-63
       return exp_(normal_logcdf_z((-x + k.mu) / k.sigma));
     } else if constexpr (FN == M355_CDF) {  // normal.py:46-47

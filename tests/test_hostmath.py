@@ -65,18 +65,8 @@ def vec(lib, name, *arrs):
 
 
 HOST_FNS = {
-    "normal": ["logpdf", "pdf", "cdf"],  # erfcx / erfinv exist only in the device libm
-    "gamma": list(FN),
-    "beta": list(FN),
-    "studentt": list(FN),
-    "poisson": ["logpdf", "pdf", "cdf", "sf", "logcdf", "logsf", "ppf", "isf"],
-    "binomial": ["logpdf", "pdf", "cdf", "sf", "logcdf", "logsf", "ppf", "isf"],
-    # erfcx / erfinv exist only in the device libm: the functions built on them are GPU-tested only
-    "lognormal": ["logpdf", "pdf", "cdf"],
-    "halfnormal": ["logpdf", "pdf", "cdf", "logcdf", "sf", "logsf"],
-    "moyal": ["logpdf", "pdf", "cdf", "logcdf", "sf", "logsf"],
-    "logitnormal": ["logpdf", "pdf", "cdf"],
-    # erfinv / erfcinv exist only in the device libm (ppf / isf of truncatednormal: GPU-tested)
+    # erfcinv exists only in the device libm (ppf / isf of truncatednormal: GPU-tested); erfcx / erfinv are the
+    # hand-written ones of m355_special.h and run here too
     "truncatednormal": ["logpdf", "pdf", "cdf", "logcdf", "sf", "logsf"],
 }
 for _name in DIST:
@@ -113,6 +103,32 @@ def test_host_log_log1p(hostlib):
     got = vec(hostlib, "hm_log1p", w)
     with np.errstate(all="ignore"):
         assert np.all(_close(got, exp, 1e-15) | (np.abs(got - exp) <= 6e-16 * np.abs(exp)))
+
+
+def test_host_erfcx_erfinv(hostlib):
+    """The hand-written erfcx (one polynomial in (a-4)/(a+4) on the half line) and erfinv (Giles' split in
+    w = -log(1-x^2)) against SciPy: relative error far inside 1e-12, special values exact."""
+    rng = np.random.default_rng(8)
+    x = np.concatenate([rng.uniform(-5, 30, 200000), np.exp(rng.uniform(-40, 40, 50000)), -np.exp(rng.uniform(-40, 3.2, 50000)),
+                        [0.0, -0.0, np.inf, -26.0, -27.0, 1e300, np.nan]])
+    with np.errstate(all="ignore"):
+        got, exp = vec(hostlib, "hm_erfcx", x), sp.erfcx(x)
+    fin = np.isfinite(exp)
+    # x < 0: SciPy's 2 exp(x^2) - erfcx(-x) rounds x^2 before the exponential (x^2 * 1.1e-16 relative; ours splits
+    # x^2 exactly and stays at 1e-16 against mpmath), hence the x^2 term of the allowance
+    # (design accuracy of erfcx_pos: 2.8e-15, the degree-20 polynomial)
+    tol = 1e-14 + np.where(x < 0, 2.3e-16 * x * x, 0.0)
+    assert np.all(np.abs(got[fin] - exp[fin]) <= tol[fin] * np.abs(exp[fin]))
+    assert np.array_equal(np.isnan(got), np.isnan(exp)) and np.array_equal(np.isposinf(got), np.isposinf(exp))
+    assert got[x == np.inf][0] == 0.0
+    q = np.concatenate([rng.uniform(-1, 1, 200000), 1 - np.exp(rng.uniform(-36.7, 0, 50000)), np.exp(rng.uniform(-36.7, 0, 50000)) - 1,
+                        np.exp(rng.uniform(-300, 0, 20000)), [0.0, 1.0, -1.0, 1 - 2.0**-53, 2.0**-53 - 1, 1.5, -2.0, np.nan, 5e-324]])
+    with np.errstate(all="ignore"):
+        got, exp = vec(hostlib, "hm_erfinv", q), sp.erfinv(q)
+    fin = np.isfinite(exp)
+    assert np.all(np.abs(got[fin] - exp[fin]) <= 4e-15 * np.abs(exp[fin])), np.max(np.abs(got[fin] - exp[fin]) / np.abs(exp[fin]))
+    assert np.array_equal(got[~fin & ~np.isnan(exp)], exp[~fin & ~np.isnan(exp)])  # +-inf at +-1
+    assert np.array_equal(np.isnan(got), np.isnan(exp))  # |x| > 1 and NaN
 
 
 def test_host_streaming_logs(hostlib):
