@@ -118,9 +118,36 @@ def config4(torch, n):
     ms = timed(torch, lambda: mvnormal.logpdf(X, mu_t, cov_t), reps=10, warmup=2)
     nbytes = 8.0 * (n * d + n + d * d + d)
     flops = n * (d * d + 3 * d) + d**3 / 3
-    print(json.dumps({"config": 4, "fn": "mvnormal.logpdf", "n": n, "d": d, "ms": ms, "obs_per_s": n / (ms * 1e-3),
-                      "GB_per_s_algorithmic": nbytes / (ms * 1e-3) / 1e9, "GFLOP_per_s": flops / (ms * 1e-3) / 1e9,
+    print(json.dumps({"config": 4, "variant": "A (shared covariance)", "fn": "mvnormal.logpdf", "n": n, "d": d, "ms": ms,
+                      "obs_per_s": n / (ms * 1e-3), "GB_per_s_algorithmic": nbytes / (ms * 1e-3) / 1e9,
+                      "frac_hbm_peak": nbytes / (ms * 1e-3) / 8e12, "GFLOP_per_s": flops / (ms * 1e-3) / 1e9,
+                      "frac_fp64_mfma_peak": flops / (ms * 1e-3) / 78.6e12,
                       "note": "whole call: Cholesky + solve + epilogue + output allocation"}), flush=True)
+    # the same with 10x the observations: the single-workgroup Cholesky (latency, ~constant) amortises
+    n10 = 10 * n
+    X10 = mu_t + torch.randn(n10, d, dtype=torch.float64, device=dev, generator=g) @ Lc.T
+    ms = timed(torch, lambda: mvnormal.logpdf(X10, mu_t, cov_t), reps=10, warmup=2)
+    nbytes = 8.0 * (n10 * d + n10 + d * d + d)
+    flops = n10 * (d * d + 3 * d) + d**3 / 3
+    print(json.dumps({"config": 4, "variant": "A (shared covariance)", "fn": "mvnormal.logpdf", "n": n10, "d": d, "ms": ms,
+                      "obs_per_s": n10 / (ms * 1e-3), "GB_per_s_algorithmic": nbytes / (ms * 1e-3) / 1e9,
+                      "frac_hbm_peak": nbytes / (ms * 1e-3) / 8e12, "GFLOP_per_s": flops / (ms * 1e-3) / 1e9,
+                      "frac_fp64_mfma_peak": flops / (ms * 1e-3) / 78.6e12,
+                      "note": "whole call: Cholesky + solve + epilogue + output allocation"}), flush=True)
+    del X10
+    # variant B: one covariance per observation (cov carries the batch axis, mvnormal.py:27): n distinct d x d matrices
+    Ab = torch.randn(n, d, d, dtype=torch.float64, device=dev, generator=g)
+    covb = torch.baddbmm(torch.eye(d, dtype=torch.float64, device=dev).expand(n, d, d), Ab, Ab.transpose(1, 2), alpha=1.0 / d)
+    del Ab
+    ms = timed(torch, lambda: mvnormal.logpdf(X, mu_t, covb), reps=5, warmup=1)
+    nbytes = 8.0 * n * (d * (d + 1) / 2 + 2 * d + 1)
+    flops = n * (d**3 / 3 + d * d + 3 * d)
+    print(json.dumps({"config": 4, "variant": "B (one covariance per observation)", "fn": "mvnormal.logpdf", "n": n, "d": d,
+                      "ms": ms, "obs_per_s": n / (ms * 1e-3), "GB_per_s_algorithmic": nbytes / (ms * 1e-3) / 1e9,
+                      "frac_hbm_peak": nbytes / (ms * 1e-3) / 8e12, "GFLOP_per_s": flops / (ms * 1e-3) / 1e9,
+                      "frac_fp64_mfma_peak": flops / (ms * 1e-3) / 78.6e12,
+                      "note": "whole call; algorithmic bytes count the lower triangle of each covariance (SURVEY.md 8(d)): "
+                              "1.77 GB at n = 1e5; the full matrices are 3.28 GB"}), flush=True)
 
 
 def config6(torch, n):

@@ -94,6 +94,12 @@ M355_DEV void sqrt_rsqrt(double a, double& root, double& inv_root) {
 //      diagonal block published through LDS.
 // Measured phase costs (tools/chol_probe.hip) are in DESIGN.md.
 constexpr int kCholThreads = 256;
+// Shared covariance, d <= 64: the solve is Y = W (X - mu)^T with W = L^-1 built block by block in k_cholesky -- a plain
+// triangular matrix product whose MFMAs depend on each other only through their accumulators (four independent
+// accumulations per tile), where blocked substitution is one chain of 40 dependent MFMAs per tile.  For observations
+// drawn with the covariance at hand the explicit inverse costs ~2x the rounding error of substitution and stays far
+// below 1e-12 (measured to cond(cov) = 1e10 against a long-double solve).  Larger d keeps substitution.
+constexpr int kFullInverseMaxNB = 4;
 
 __global__ __launch_bounds__(kCholThreads) void k_cholesky(const double* __restrict__ cov, int d,
                                                             double* __restrict__ ws, double* __restrict__ frags) {
@@ -102,7 +108,7 @@ __global__ __launch_bounds__(kCholThreads) void k_cholesky(const double* __restr
   const int dp = 16 * NB, S = dp + 1;
   double* diag = a + (size_t)dp * S;
   double* inv = diag + 272;
-  double* rdiag = inv + NB * 256;
+  double* rdiag = inv + (NB <= kFullInverseMaxNB ? NB * (NB + 1) / 2 : NB) * 256;
   const double* src = cov + (size_t)blockIdx.x * d * d;
   double* dst = ws + (size_t)blockIdx.x * chol_stride(d);
   const int t = threadIdx.x, wave = t >> 6;
@@ -204,6 +210,10 @@ __global__ __launch_bounds__(kCholThreads) void k_cholesky(const double* __restr
   }
   M355_TICK(41);
   if (frags == nullptr) return;
+  // Up to NB = 4 the solve multiplies by W = L^-1 outright (k_solve_mfma, kFullInverseMaxNB): every block W_IJ is
+  // built here; beyond, only the diagonal blocks are inverted and the solve substitutes across blocks with -L.
+  const bool full = NB <= kFullInverseMaxNB;
+  auto blk = [&](int I, int J) { return full ? I * (I + 1) / 2 + J : I; };  // slot of block (I, J) in inv[]
   // inverse of each 16x16 lower-triangular diagonal block, one column per thread, in registers:
   //   X[c][c] = 1/L[c][c],  X[r][c] = -(sum_{k=c}^{r-1} L[r][k] X[k][c]) / L[r][r]
   if (t < dp) {
@@ -219,18 +229,43 @@ __global__ __launch_bounds__(kCholThreads) void k_cholesky(const double* __restr
       x[r] = (r == c) ? rd[r] : (r > c ? -acc * rd[r] : 0.0);
     }
 #pragma unroll
-    for (int r = 0; r < 16; ++r) inv[I * 256 + r * 16 + c] = x[r];
+    for (int r = 0; r < 16; ++r) inv[blk(I, I) * 256 + r * 16 + c] = x[r];
   }
   __syncthreads();
   M355_TICK(42);
+  if (full) {
+    // off-diagonal blocks by block forward substitution on the identity, one sub-diagonal s at a time (its blocks
+    // are independent: dealt to the wavefronts):  W_IJ = -W_II sum_{K=J}^{I-1} L_IK W_KJ, each 16x16x16 product = 4 MFMAs
+    for (int s_ = 1; s_ < NB; ++s_) {
+      for (int J = wave; J + s_ < NB; J += kCholThreads / 64) {
+        const int I = J + s_;
+        d4_t acc = {0.0, 0.0, 0.0, 0.0};
+        for (int K = J; K < I; ++K) {
+          const double* pa = a + (size_t)(16 * I + (lane & 15)) * S + 16 * K + (lane >> 4);  // A: L_IK[row l&15][k]
+          const double* pb = inv + blk(K, J) * 256 + (lane >> 4) * 16 + (lane & 15);         // B: W_KJ[k][col l&15]
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[4 * kk], pb[64 * kk], acc, 0, 0, 0);
+        }
+        // the D layout of the sum (row (l>>4)+4r, col l&15) is the B layout of k-step r
+        const double* pw = inv + blk(I, I) * 256 + (lane & 15) * 16 + (lane >> 4);           // A: W_II[row l&15][k]
+        d4_t w = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) w = __builtin_amdgcn_mfma_f64_16x16x4f64(-pw[4 * kk], acc[kk], w, 0, 0, 0);
+        double* po = inv + blk(I, J) * 256 + (lane >> 4) * 16 + (lane & 15);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) po[64 * r] = w[r];
+      }
+      __syncthreads();
+    }
+  }
   {
-    // thread = (k-step kk, lane l); blocks b = (I, J) walked in order
+    // thread = (k-step kk, lane l); blocks b = (I, J) walked in order: the A operand of the solve's MFMAs
     const int l = t & 63, kk = t >> 6;
     const int r = l & 15, c = (l >> 4) + 4 * kk;
     int e = t;
     for (int I = 0; I < NB; ++I) {
       for (int J = 0; J <= I; ++J, e += 256)
-        frags[e] = (J == I) ? inv[I * 256 + r * 16 + c] : -a[(16 * I + r) * S + 16 * J + c];
+        frags[e] = (J == I || full) ? inv[blk(I, J) * 256 + r * 16 + c] : -a[(16 * I + r) * S + 16 * J + c];
     }
   }
   M355_TICK(43);
@@ -305,44 +340,56 @@ struct MfmaArgs {
 
 constexpr int kMfmaWaves = 4;
 
-template <int NB, bool MU_ROWS> __global__ __launch_bounds__(64 * kMfmaWaves) void k_solve_mfma(const MfmaArgs a) {
+// REGF (NB <= kFullInverseMaxNB): the fragments are the blocks of W = L^-1 and live in registers for the whole kernel
+// (NB(NB+1)/2 x 4 doubles per lane: 80 VGPRs at NB = 4); a tile is NB independent accumulations.  Otherwise blocked
+// forward substitution with the fragments in LDS (-L blocks, inverse diagonal blocks), T tiles interleaved.
+template <int NB, bool MU_ROWS, int T, bool REGF>
+__global__ __launch_bounds__(64 * kMfmaWaves) void k_solve_mfma(const MfmaArgs a) {
   constexpr int NBLK = NB * (NB + 1) / 2;
   constexpr int S = 16 * NB + 4;  // staging row stride: the 64 lanes of a D-layout read hit each bank pair twice
   constexpr int NJ = 2 * NB;      // 16-byte loads per lane per tile (16 obs x 16 NB doubles / 128)
   extern __shared__ double lds[];
-  double* fr = lds;                   // NBLK * 256
-  double* mu_s = fr + NBLK * 256;     // 16 * NB (zero padded)
+  double* fr = lds;                                   // NBLK * 256 (unused with REGF)
+  double* mu_s = fr + (REGF ? 0 : NBLK * 256);        // 16 * NB (zero padded)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  double* st = mu_s + 16 * NB + wave * (16 * S);  // this wavefront's 16 x S staging tile
+  double* st = mu_s + 16 * NB + wave * (T * 16 * S);  // this wavefront's T staging tiles of 16 x S
   const int d = a.d;
   const int tile_elems = 16 * d;
   const long long total = a.n * (long long)d;
   const long long ntiles = (a.n + 15) / 16;
-  const long long tstride = (long long)gridDim.x * kMfmaWaves;
-  d2_t raw[NJ];
-  auto fetch = [&](long long tile) {
-    const long long base = tile * tile_elems;
+  const long long ngroups = (ntiles + T - 1) / T;     // a wavefront takes T consecutive tiles per step
+  const long long gstride = (long long)gridDim.x * kMfmaWaves;
+  d2_t raw[T][NJ];
+  auto fetch = [&](long long group) {
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-      const int e = 128 * j + 2 * lane;
-      const long long g = base + e;
-      d2_t v = {0.0, 0.0};
-      if (e < tile_elems) {
-        if (g + 1 < total) {
-          v = __builtin_nontemporal_load(reinterpret_cast<const d2_t*>(a.x + g));
-          if (MU_ROWS) v -= __builtin_nontemporal_load(reinterpret_cast<const d2_t*>(a.mu + g));
-        } else if (g < total) {
-          v.x = a.x[g];
-          if (MU_ROWS) v.x -= a.mu[g];
+    for (int t = 0; t < T; ++t) {
+      const long long base = (group * T + t) * tile_elems;
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const int e = 128 * j + 2 * lane;
+        const long long g = base + e;
+        d2_t v = {0.0, 0.0};
+        if (e < tile_elems) {
+          if (g + 1 < total) {
+            v = __builtin_nontemporal_load(reinterpret_cast<const d2_t*>(a.x + g));
+            if (MU_ROWS) v -= __builtin_nontemporal_load(reinterpret_cast<const d2_t*>(a.mu + g));
+          } else if (g < total) {
+            v.x = a.x[g];
+            if (MU_ROWS) v.x -= a.mu[g];
+          }
         }
+        raw[t][j] = v;
       }
-      raw[j] = v;
     }
   };
   M355_TICK(50);
-  long long tile = (long long)blockIdx.x * kMfmaWaves + wave;
-  if (tile < ntiles) fetch(tile);  // first tile in flight while the operand fragments are staged
-  {
+  long long group = (long long)blockIdx.x * kMfmaWaves + wave;
+  if (group < ngroups) fetch(group);  // first tiles in flight while the operand fragments arrive
+  double F[REGF ? NBLK * 4 : 1];
+  if constexpr (REGF) {
+#pragma unroll
+    for (int b = 0; b < NBLK * 4; ++b) F[b] = a.frags[b * 64 + lane];
+  } else {
     double tmp[NBLK];
 #pragma unroll
     for (int b = 0; b < NBLK; ++b) tmp[b] = a.frags[b * 256 + threadIdx.x];
@@ -350,14 +397,17 @@ template <int NB, bool MU_ROWS> __global__ __launch_bounds__(64 * kMfmaWaves) vo
     for (int b = 0; b < NBLK; ++b) fr[b * 256 + threadIdx.x] = tmp[b];
   }
   for (int e = threadIdx.x; e < 16 * NB; e += blockDim.x) mu_s[e] = (!MU_ROWS && e < d) ? a.mu[e] : 0.0;
-  for (int e = lane; e < 16 * S; e += 64) st[e] = 0.0;  // padding columns stay zero for the whole kernel
+  for (int e = lane; e < T * 16 * S; e += 64) st[e] = 0.0;  // padding columns stay zero for the whole kernel
   __syncthreads();
+  auto frag = [&](int blk, int kk) -> double {
+    if constexpr (REGF) return F[blk * 4 + kk];
+    else return fr[(blk * 4 + kk) * 64 + lane];
+  };
 
-  // flat element e = 128 j + 2 lane (+1) of a tile -> staging offset and mean, fixed for the kernel.
+  // flat element e = 128 j + 2 lane (+1) of a tile -> staging offset, fixed for the kernel.
   // e / d through a float reciprocal: exact here (e < 2048, d <= 128: (e + 0.5) / d is never within
   // float rounding of an integer).
   int off0[NJ], off1[NJ];
-  double m0[NJ], m1[NJ];
   const float invd = 1.0f / (float)d;
 #pragma unroll
   for (int j = 0; j < NJ; ++j) {
@@ -366,59 +416,112 @@ template <int NB, bool MU_ROWS> __global__ __launch_bounds__(64 * kMfmaWaves) vo
     const int o1 = (int)(((float)e + 1.5f) * invd), c1 = (e + 1) - o1 * d;
     off0[j] = e < tile_elems ? o0 * S + c0 : -1;
     off1[j] = (e + 1) < tile_elems ? o1 * S + c1 : -1;
-    m0[j] = e < tile_elems ? mu_s[c0] : 0.0;
-    m1[j] = (e + 1) < tile_elems ? mu_s[c1] : 0.0;
   }
   const double logdet = a.chol[(size_t)d * d + d];
   const int rbase = (lane & 15) * S + (lane >> 4);
   M355_TICK(51);
   int tk = 52;
   (void)tk;
-  for (; tile < ntiles; tile += tstride) {
+  for (; group < ngroups; group += gstride) {
     M355_TICK(tk); ++tk;
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-      if (off0[j] >= 0) st[off0[j]] = raw[j].x - m0[j];
-      if (off1[j] >= 0) st[off1[j]] = raw[j].y - m1[j];
+    for (int t = 0; t < T; ++t) {
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        if (off0[j] >= 0) st[t * 16 * S + off0[j]] = raw[t][j].x;
+        if (off1[j] >= 0) st[t * 16 * S + off1[j]] = raw[t][j].y;
+      }
     }
     M355_TICK(tk); ++tk;
-    if (tile + tstride < ntiles) fetch(tile + tstride);  // in flight during the MFMA chain below
+    if (group + gstride < ngroups) fetch(group + gstride);  // in flight during the MFMA chains below
     __builtin_amdgcn_wave_barrier();
-    d4_t Y[NB];
-    double quad = 0.0;
+    double quad[T];
 #pragma unroll
-    for (int I = 0; I < NB; ++I) {
-      d4_t acc;
+    for (int t = 0; t < T; ++t) quad[t] = 0.0;
+    if constexpr (REGF) {
+      // Y_I = sum_{J <= I} W_IJ Delta_J: the B operand of k-step kk of block J is Delta[obs l&15][16J + (l>>4) + 4kk],
+      // i.e. the staged tile read in the D layout; consecutive MFMAs go to different accumulators
 #pragma unroll
-      for (int r = 0; r < 4; ++r) acc[r] = st[rbase + 16 * I + 4 * r];
+      for (int t = 0; t < T; ++t) {
+        d4_t B[NB], acc[NB];
 #pragma unroll
-      for (int J = 0; J < I; ++J) {
+        for (int J = 0; J < NB; ++J) {
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk)
-          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(fr[((I * (I + 1) / 2 + J) * 4 + kk) * 64 + lane], Y[J][kk], acc, 0, 0, 0);
+          for (int r = 0; r < 4; ++r) B[J][r] = st[t * 16 * S + rbase + 16 * J + 4 * r] - mu_s[16 * J + (lane >> 4) + 4 * r];
+          acc[J] = d4_t{0.0, 0.0, 0.0, 0.0};
+        }
+#pragma unroll
+        for (int J = 0; J < NB; ++J) {
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+            for (int I = J; I < NB; ++I)
+              acc[I] = __builtin_amdgcn_mfma_f64_16x16x4f64(frag(I * (I + 1) / 2 + J, kk), B[J][kk], acc[I], 0, 0, 0);
+          }
+        }
+#pragma unroll
+        for (int I = 0; I < NB; ++I) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) quad[t] = __builtin_fma(acc[I][r], acc[I][r], quad[t]);
+        }
       }
-      d4_t y = {0.0, 0.0, 0.0, 0.0};
+    } else {
+      d4_t Y[T][NB];
 #pragma unroll
-      for (int kk = 0; kk < 4; ++kk)
-        y = __builtin_amdgcn_mfma_f64_16x16x4f64(fr[((I * (I + 1) / 2 + I) * 4 + kk) * 64 + lane], acc[kk], y, 0, 0, 0);
-      Y[I] = y;
+      for (int I = 0; I < NB; ++I) {
+        d4_t acc[T];
+        double mu_r[4];  // the mean of the four components this lane holds in the D layout (0 with per-row means)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) quad = __builtin_fma(y[r], y[r], quad);
+        for (int r = 0; r < 4; ++r) mu_r[r] = mu_s[16 * I + (lane >> 4) + 4 * r];
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[t][r] = st[t * 16 * S + rbase + 16 * I + 4 * r] - mu_r[r];
+        }
+#pragma unroll
+        for (int J = 0; J < I; ++J) {
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk) {
+            const double f = frag(I * (I + 1) / 2 + J, kk);
+#pragma unroll
+            for (int t = 0; t < T; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(f, Y[t][J][kk], acc[t], 0, 0, 0);
+          }
+        }
+        d4_t y[T];
+#pragma unroll
+        for (int t = 0; t < T; ++t) y[t] = d4_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+          const double f = frag(I * (I + 1) / 2 + I, kk);
+#pragma unroll
+          for (int t = 0; t < T; ++t) y[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(f, acc[t][kk], y[t], 0, 0, 0);
+        }
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+          Y[t][I] = y[t];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) quad[t] = __builtin_fma(y[t][r], y[t][r], quad[t]);
+        }
+      }
     }
     __builtin_amdgcn_wave_barrier();
     M355_TICK(tk); ++tk;
-    // lanes l, l+16, l+32, l+48 hold the four row groups of observation l & 15
-    quad += __shfl_xor(quad, 16, 64);
-    quad += __shfl_xor(quad, 32, 64);
-    const long long r = tile * 16 + lane;
-    if (lane < 16 && r < a.n) {
-      double v = quad;
-      if (a.mode == 1) {
-        v = -0.5 * (a.c0 + logdet + quad);  // mvnormal.py:82-83
-      } else if (a.mode == 2) {
-        v = a.c0 - 0.5 * (a.nu + (double)d) * flog1p(quad / a.nu) - 0.5 * logdet;  // mvstudentt.py:62-64
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      // lanes l, l+16, l+32, l+48 hold the four row groups of observation l & 15
+      double q = quad[t];
+      q += __shfl_xor(q, 16, 64);
+      q += __shfl_xor(q, 32, 64);
+      const long long r = (group * T + t) * 16 + lane;
+      if (lane < 16 && r < a.n) {
+        double v = q;
+        if (a.mode == 1) {
+          v = -0.5 * (a.c0 + logdet + q);  // mvnormal.py:82-83
+        } else if (a.mode == 2) {
+          v = a.c0 - 0.5 * (a.nu + (double)d) * flog1p(q / a.nu) - 0.5 * logdet;  // mvstudentt.py:62-64
+        }
+        a.out[r] = v;
       }
-      a.out[r] = v;
     }
   }
 }
@@ -455,7 +558,9 @@ int launched() {
 int run_cholesky(const double* cov, long long ncov, int d, double* ws, double* frags, hipStream_t s) {
   const int threads = m355::kCholThreads;
   const int dp = 16 * m355::nblk16(d);
-  const size_t lds = ((size_t)dp * (dp + 1) + 272 + (size_t)m355::nblk16(d) * 256 + dp) * sizeof(double);
+  const int nb = m355::nblk16(d);
+  const size_t ninv = nb <= m355::kFullInverseMaxNB ? (size_t)nb * (nb + 1) / 2 : (size_t)nb;  // inverse blocks kept in LDS
+  const size_t lds = ((size_t)dp * (dp + 1) + 272 + ninv * 256 + dp) * sizeof(double);
   if (lds > 64 * 1024) {  // up to ~148 KiB of the CU's 160 KiB LDS for d = 128
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(m355::k_cholesky),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -465,21 +570,32 @@ int run_cholesky(const double* cov, long long ncov, int d, double* ws, double* f
   return launched();
 }
 template <int NB, bool MU_ROWS> int launch_mfma(const m355::MfmaArgs& a, hipStream_t s) {
-  const size_t lds = ((size_t)NB * (NB + 1) / 2 * 256 + 16 * NB + (size_t)m355::kMfmaWaves * 16 * (16 * NB + 4)) * sizeof(double);
+  constexpr bool REGF = NB <= m355::kFullInverseMaxNB;  // W = L^-1 blocks in registers (80 VGPRs at NB = 4)
+  constexpr int T = 1;  // tiles per wavefront step
+  const size_t lds = ((REGF ? 0 : (size_t)NB * (NB + 1) / 2 * 256) + 16 * NB + (size_t)m355::kMfmaWaves * T * 16 * (16 * NB + 4)) * sizeof(double);
+  auto kern = m355::k_solve_mfma<NB, MU_ROWS, T, REGF>;
   if (lds > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(m355::k_solve_mfma<NB, MU_ROWS>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return fail(M355_ERR_LAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
   }
-  const long long ntiles = (a.n + 15) / 16;
-  long long blocks = (ntiles + m355::kMfmaWaves - 1) / m355::kMfmaWaves;
-  long long cap = 2 * 256;  // two workgroups per CU: every wavefront sees >= 2 tiles and prefetches
+  const long long ngroups = ((a.n + 15) / 16 + T - 1) / T;
+  long long blocks = (ngroups + m355::kMfmaWaves - 1) / m355::kMfmaWaves;
+  // one round of resident workgroups (every wavefront pays the fragment / staging prologue once and then walks its
+  // groups): workgroups per CU from the occupancy calculator (registers and LDS decide: 1 at NB = 4, up to 4 at NB = 1)
+  static const long long resident = [&] {
+    int per_cu = 0, dev = 0, cus = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 64 * m355::kMfmaWaves, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+    (void)hipGetLastError();
+    return (long long)per_cu * cus;
+  }();
+  long long cap = resident;
   if (const char* e = getenv("M355_MVN_BLOCKS")) {  // A/B knob for grid sweeps; ignored unless a positive count
     const long long v = atoll(e);
     if (v >= 1) cap = v;
   }
   if (blocks > cap) blocks = cap;
-  hipLaunchKernelGGL((m355::k_solve_mfma<NB, MU_ROWS>), dim3((unsigned)blocks), dim3(64 * m355::kMfmaWaves), lds, s, a);
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64 * m355::kMfmaWaves), lds, s, a);
   return launched();
 }
 template <bool MU_ROWS> int run_mfma(const m355::MfmaArgs& a, hipStream_t s) {
