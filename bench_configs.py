@@ -66,6 +66,43 @@ def config2(torch, n):
         print(json.dumps({"config": 2, "fn": label, "n": rows * 1024, "layout": "params (1024,) row-periodic, LDS-staged "
                           "(time includes torch.empty of the output)", "ms": ms, "evals_per_s": rows * 1024 / (ms * 1e-3),
                           "GB_per_s_algorithmic": 16.0 * rows * 1024 / (ms * 1e-3) / 1e9}), flush=True)
+    # the special-function functions with the same row-periodic parameters (config 2 as written): through the C-ABI
+    # into a preallocated output, periodic operands
+    periodic_special(torch, xs, q, out, rows)
+
+
+def periodic_special(torch, xs, q, out, rows):
+    import ctypes
+
+    from distributions_amd import _lib
+    from distributions_amd._lib import DIST, F64, FN, Operand
+
+    L = _lib.lib()
+    dev = out.device
+    P = 1024
+    n = rows * P
+    lin = lambda lo, hi: torch.linspace(lo, hi, P, dtype=torch.float64, device=dev)
+    cases = {"gamma": (lin(0.5, 9.0), lin(0.3, 3.0)), "beta": (lin(0.5, 9.0), lin(1.0, 10.0)),
+             "studentt": (lin(2.0, 30.0), 0.0, 2.0)}
+    stream = torch.cuda.current_stream(dev).cuda_stream
+
+    def call(name, fn, src, params):
+        ops = (Operand * (1 + len(params)))()
+        ops[0].ptr, ops[0].div, ops[0].mod, ops[0].dtype = src.data_ptr(), 1, n, F64
+        for j, p in enumerate(params, start=1):
+            if isinstance(p, float):
+                ops[j].ptr, ops[j].scalar, ops[j].div, ops[j].mod, ops[j].dtype = None, p, 1, 1, F64
+            else:
+                ops[j].ptr, ops[j].scalar, ops[j].div, ops[j].mod, ops[j].dtype = p.data_ptr(), 0.0, 1, P, F64
+        at = lambda k: ctypes.cast(ctypes.byref(ops, k * ctypes.sizeof(Operand)), ctypes.POINTER(Operand))
+        _lib.check(L.m355_elemwise(DIST[name], FN[fn], F64, n, at(0), len(params), at(1), out.data_ptr(), stream))
+
+    for name, params in cases.items():
+        for fn in ("logpdf", "logcdf", "ppf"):
+            src = q if fn == "ppf" else xs[name]
+            ms = timed(torch, lambda: call(name, fn, src, params), reps=3)
+            print(json.dumps({"config": 2, "fn": f"{name}.{fn}", "n": n, "layout": "params (1024,) row-periodic", "ms": ms,
+                              "evals_per_s": n / (ms * 1e-3), "GB_per_s_algorithmic": 16.0 * n / (ms * 1e-3) / 1e9}), flush=True)
 
 
 def config3(torch, n):

@@ -426,6 +426,174 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(min_wave
     store1(out, odt, i, DD::template eval<FN>(load1(x, xdt, i), k));
 }
 
+// ------------------------------------------------------------------------------------------------
+// k_colbinned: the same idea for row-periodic parameters (x of shape (R, P), parameters of shape (P,): "config 2,
+// broadcast params").  In memory order every lane of a wavefront has its own parameter set, so sorting by x alone
+// groups nothing; but a COLUMN of x shares one parameter set.  A workgroup therefore takes a tile of 512 rows x 8
+// columns (each row's 8 values are 64 contiguous bytes), sorts each column's 512 values by x in LDS (64 buckets,
+// counting sort) and evaluates column by column: the whole workgroup runs one parameter set at a time (its derived
+// constants uniform, read once from LDS into scalar registers) and each wavefront pass holds one octile of that
+// column's x.  Results return through LDS to their rows and leave as 64-byte row segments.  A workgroup keeps its 8 columns for
+// all the row blocks it walks, so the 8 derive() calls (lgamma, log ...) happen once per workgroup.
+constexpr int kColW = 8;         // columns per tile
+constexpr int kColPer = 2;       // rows per thread
+constexpr int kColRows = kColPer * kBlock;  // rows per tile: 512 values per column = 8 wavefront passes (octiles of x)
+constexpr int kColBuckets = 64;
+
+M355_DEV double uniform_d(double v) {  // v is wave-uniform: move it to scalar registers
+#if defined(__HIP_DEVICE_COMPILE__)
+  const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)b);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(b >> 32));
+  return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+#else
+  return v;
+#endif
+}
+
+template <int D, int FN>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(min_waves<Dist<D>>::value))) void k_colbinned(
+    const void* __restrict__ x, int xdt, void* __restrict__ out, int odt, long long row_blocks, unsigned P, PeriodicParams pa) {
+  using DD = Dist<D>;
+  using K = typename DD::K;
+  constexpr int NK = sizeof(K) / sizeof(double);
+  constexpr int NV = kColPer * kColW;  // values per thread: row t + 256 p, column c at v[p * kColW + c]
+  __shared__ double xs[kColW * kColRows];
+  __shared__ unsigned cnt[kColW * kColBuckets];
+  __shared__ double kt[kColW * NK];
+  __shared__ unsigned red_min[kBlock / 64][kColW], red_max[kBlock / 64][kColW];
+  if constexpr (uses_log_table<DD>::value && (FN == M355_LOGPDF || FN == M355_PDF)) log_table_init();
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const unsigned G = P / kColW;
+  const unsigned g = blockIdx.x % G;                               // this workgroup's column group, for all its tiles
+  const long long rb0 = blockIdx.x / G, rbstep = gridDim.x / G;    // (gridDim.x is a multiple of G)
+  if (t < kColW) {
+    double pp[kMaxParams];
+#pragma unroll
+    for (int q = 0; q < kMaxParams; ++q) pp[q] = (q < DD::NP && pa.ptr[q]) ? pa.ptr[q][g * kColW + t] : pa.scalar[q];
+    const K k = DD::derive(pp);
+    const double* kd = reinterpret_cast<const double*>(&k);
+#pragma unroll
+    for (int f = 0; f < NK; ++f) kt[t * NK + f] = kd[f];
+  }
+  __syncthreads();
+  for (long long rb = rb0; rb < row_blocks; rb += rbstep) {
+    const long long base = (rb * kColRows + t) * (long long)P + (long long)g * kColW;
+    double v[NV];
+#pragma unroll
+    for (int p = 0; p < kColPer; ++p) {
+#pragma unroll
+      for (int j = 0; j < kColW; j += 2)
+        load2<0>(x, xdt, base + (long long)p * kBlock * P + j, v[p * kColW + j], v[p * kColW + j + 1]);
+    }
+    // 32-bit sort key per value: the high word of sign(x) (1 + |x|) read as an ordered integer (linear in x below 1,
+    // logarithmic above; NaN -> 0); per-column minimum / maximum over the tile's rows
+    unsigned key[NV], kmin[kColW], kmax[kColW];
+#pragma unroll
+    for (int c = 0; c < kColW; ++c) {
+      kmin[c] = ~0u;
+      kmax[c] = 0u;
+    }
+#pragma unroll
+    for (int e = 0; e < NV; ++e) {
+      double tt = __builtin_fabs(v[e]);
+      tt = tt < 0x1p500 ? tt : ((tt == tt) ? 0x1p500 : 0.0);
+      const int mag = (int)((__builtin_bit_cast(unsigned long long, 1.0 + tt) - 0x3ff0000000000000ull) >> 32);
+      key[e] = (unsigned)((v[e] < 0.0 ? -mag : mag) + (1 << 30));
+      kmin[e % kColW] = key[e] < kmin[e % kColW] ? key[e] : kmin[e % kColW];
+      kmax[e % kColW] = key[e] > kmax[e % kColW] ? key[e] : kmax[e % kColW];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+      for (int c = 0; c < kColW; ++c) {
+        const unsigned a_ = __shfl_xor(kmin[c], o, 64), b_ = __shfl_xor(kmax[c], o, 64);
+        kmin[c] = a_ < kmin[c] ? a_ : kmin[c];
+        kmax[c] = b_ > kmax[c] ? b_ : kmax[c];
+      }
+    }
+    if (lane < kColW) {
+      unsigned mn = kmin[0], mx = kmax[0];
+#pragma unroll
+      for (int c = 1; c < kColW; ++c) {
+        mn = lane == c ? kmin[c] : mn;
+        mx = lane == c ? kmax[c] : mx;
+      }
+      red_min[wave][lane] = mn;
+      red_max[wave][lane] = mx;
+    }
+    cnt[t] = 0u;
+    cnt[t + kBlock] = 0u;  // kColW * kColBuckets == 2 * kBlock
+    __syncthreads();
+    unsigned bucket[NV], rank[NV];
+#pragma unroll
+    for (int c = 0; c < kColW; ++c) {
+      unsigned mn = red_min[0][c], mx = red_max[0][c];
+#pragma unroll
+      for (int w = 1; w < kBlock / 64; ++w) {
+        mn = red_min[w][c] < mn ? red_min[w][c] : mn;
+        mx = red_max[w][c] > mx ? red_max[w][c] : mx;
+      }
+      const unsigned span = mx - mn;
+      const int shift = span >> 6 ? 32 - 6 - __builtin_clz(span) : 0;  // (span >> shift) < 64
+#pragma unroll
+      for (int p = 0; p < kColPer; ++p) {
+        const int e = p * kColW + c;
+        bucket[e] = (key[e] - mn) >> shift;
+        rank[e] = atomicAdd(&cnt[c * kColBuckets + bucket[e]], 1u);
+      }
+    }
+    __syncthreads();
+    // exclusive prefix sums of each column's 64 counters: wavefront w scans columns 2w and 2w + 1, lane = bucket
+#pragma unroll
+    for (int h = 0; h < kColW / (kBlock / 64); ++h) {
+      const int c = wave * (kColW / (kBlock / 64)) + h;
+      const unsigned cval = cnt[c * kColBuckets + lane];
+      unsigned incl = cval;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const unsigned up = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += up;
+      }
+      cnt[c * kColBuckets + lane] = incl - cval;
+    }
+    __syncthreads();
+    unsigned slot[NV];
+#pragma unroll
+    for (int e = 0; e < NV; ++e) {
+      const int c = e % kColW;
+      slot[e] = cnt[c * kColBuckets + bucket[e]] + rank[e];
+      xs[c * kColRows + slot[e]] = v[e];
+    }
+    __syncthreads();
+    // column by column, kColPer passes each; the pass / wavefront that takes a given octile of x rotates with the
+    // column, so that a systematic cost gradient along x (cheap tails, dear middle) does not always load the same
+    // wavefront (the wavefronts only meet again at the barrier after the last column)
+#pragma unroll 1
+    for (int c = 0; c < kColW; ++c) {
+      K k;
+      double* kd = reinterpret_cast<double*>(&k);
+#pragma unroll
+      for (int f = 0; f < NK; ++f) kd[f] = uniform_d(kt[c * NK + f]);
+#pragma unroll 1
+      for (int p = 0; p < kColPer; ++p) {
+        const int s_ = c * kColRows + ((p * kBlock + t + 64 * c) & (kColRows - 1));
+        xs[s_] = DD::template eval<FN>(xs[s_], k);  // in place: each slot has one reader
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < NV; ++e) v[e] = xs[(e % kColW) * kColRows + slot[e]];
+#pragma unroll
+    for (int p = 0; p < kColPer; ++p) {
+#pragma unroll
+      for (int j = 0; j < kColW; j += 2)
+        store2<0>(out, odt, base + (long long)p * kBlock * P + j, v[p * kColW + j], v[p * kColW + j + 1]);
+    }
+    __syncthreads();
+  }
+}
+
 // Dist<D>::kBinned = 1: every function but logpdf / pdf goes through k_binned; = 2: only ppf / isf (families whose
 // cdf is closed-form but whose quantile is a Newton iteration).
 template <class T, class = void> struct binning_mode { static constexpr int value = 0; };
@@ -570,14 +738,37 @@ template <int D, int FN, bool REDUCE> int launch_fn(const LaunchArgs& a) {
       pa.ptr[q] = (q < DD::NP) ? static_cast<const double*>(a.p[q].ptr) : nullptr;
       pa.scalar[q] = a.p[q].scalar;
     }
+    const void* xp = a.x.ptr;
+    void* op = a.out;
+    long long nn = n;
+    if constexpr (!REDUCE && bin_this<DD, FN>()) {
+      // divergent functions with row-periodic parameters: whole blocks of kColRows rows go through k_colbinned (sorted
+      // by x within each column); what is left (fewer than kColRows rows and a partial row) through k_periodic below
+      const long long row_blocks = !all_scalar ? (n / (long long)P) / kColRows : 0;
+      const unsigned long long G = P / kColW;
+      if (row_blocks >= 4 && P % kColW == 0 && G <= (unsigned long long)kMaxBlocks && !binning_disabled()) {
+        long long m = 2048 / (long long)G;
+        m = m < 1 ? 1 : (m > row_blocks ? row_blocks : m);
+        hipLaunchKernelGGL((k_colbinned<D, FN>), dim3((unsigned)(G * m)), dim3(kBlock), 0, a.stream, xp, a.x.dtype, op,
+                           a.out_dtype, row_blocks, (unsigned)P, pa);
+        const int rc = (int)hipGetLastError();
+        const long long done = row_blocks * kColRows * (long long)P;
+        if (rc != 0 || done == n) return rc;
+        xp = static_cast<const char*>(xp) + done * (a.x.dtype == M355_F32 ? 4 : 8);
+        op = static_cast<char*>(op) + done * (a.out_dtype == M355_F32 ? 4 : 8);
+        nn = n - done;
+        const long long t2 = nn / kTile;
+        blocks = (int)(t2 < 1 ? 1 : (t2 > blocks ? blocks : t2));
+      }
+    }
     const size_t lds = (size_t)P * sizeof(typename DD::K);
     if (f64io) {
       if constexpr (kFastIO)
         hipLaunchKernelGGL((k_periodic<D, FN, REDUCE, true>), dim3(blocks), dim3(kBlock), lds, a.stream,
-                           a.x.ptr, a.x.dtype, a.out, a.out_dtype, n, pa, (unsigned)P, a.partials);
+                           xp, a.x.dtype, op, a.out_dtype, nn, pa, (unsigned)P, a.partials);
     } else {
       hipLaunchKernelGGL((k_periodic<D, FN, REDUCE, false>), dim3(blocks), dim3(kBlock), lds, a.stream,
-                         a.x.ptr, a.x.dtype, a.out, a.out_dtype, n, pa, (unsigned)P, a.partials);
+                         xp, a.x.dtype, op, a.out_dtype, nn, pa, (unsigned)P, a.partials);
     }
   } else {
     GenericOps ops;

@@ -416,3 +416,64 @@ def test_binned_kernel_equals_scalar_kernel(gpu, name, fn, params):
     if name == "poisson":  # int64 observations through the binned path
         k = x.astype(np.int64)
         assert np.array_equal(getattr(m, fn)(k, *params), big, equal_nan=True)
+
+
+@pytest.mark.parametrize("name, fn, P", [("gamma", "logcdf", 1024), ("gamma", "ppf", 1024), ("beta", "logsf", 64), ("beta", "ppf", 8),
+                                         ("studentt", "logcdf", 1000), ("studentt", "isf", 40), ("gamma", "cdf", 1001)])
+def test_colbinned_kernel_equals_periodic_kernel(gpu, name, fn, P):
+    """k_colbinned (row-periodic parameters: 512 x 8 tiles, each column sorted by x in LDS and evaluated with its one
+    parameter set) returns bit for bit what k_periodic returns: inputs of >= 4 blocks of 512 rows take the sorted path
+    (with a k_periodic launch for the rows left over), slices of fewer rows the plain one; P = 1001 is not a
+    multiple of 8 and stays on k_periodic altogether.  Both against the oracle at 1e-12 too."""
+    rng = np.random.default_rng(52)
+    rows = 2600 if P >= 1000 else (5000 if P >= 40 else 20_000)
+    tail = 17 if P > 17 else 3  # a partial row after the last full one
+    n = rows * P + tail
+    if fn in ("ppf", "isf"):
+        x = rng.uniform(0, 1, n)
+        x[:7] = [0.0, 1.0, -0.5, 1.5, np.nan, 0.5, 1e-300]
+    elif name == "beta":
+        x = rng.uniform(-0.05, 1.05, n)
+    else:
+        x = np.abs(rng.standard_cauchy(n)) * 2 if name != "studentt" else rng.standard_cauchy(n) * 3
+        x[:6] = [0.0, np.inf, -np.inf, np.nan, -1.0, 1e-300]
+    params = {"gamma": (rng.uniform(0.3, 12.0, P), rng.uniform(0.3, 3.0, P)), "beta": (rng.uniform(0.4, 9.0, P), 2.5),
+              "studentt": (rng.uniform(1.5, 40.0, P), 0.3, rng.uniform(0.5, 2.0, P))}[name]
+    m = mod(name)
+    # the library sees x flat with parameters of period P: call through a (rows, P) view for the full rows and
+    # evaluate the partial row separately
+    body = x[: rows * P].reshape(rows, P)
+    big = getattr(m, fn)(body, *params)
+    step = 1500  # < 4 * 512 rows: k_periodic
+    parts = np.concatenate([getattr(m, fn)(body[i:i + step], *params) for i in range(0, rows, step)])
+    assert np.array_equal(big, parts, equal_nan=True)
+    with np.errstate(all="ignore"):
+        exp = R.TABLE[f"{name}_{fn}"](body, *params)
+    ok = H.ppf_close(name, fn, None, big, exp) | H.ppf_unpinned(name, fn, body)
+    assert np.all(ok), (name, fn, body[~ok][:4], big[~ok][:4], exp[~ok][:4])
+    # flat call with the partial row: the operand description (div = 1, mod = P) is what _dispatch builds for a
+    # 1-d x of length n against np.resize-d parameters -- here through raw operands
+    import ctypes
+
+    import torch
+
+    from distributions_amd import _lib
+    from distributions_amd._lib import DIST, F64, FN, Operand
+
+    xt = torch.from_numpy(x).to(gpu)
+    out = torch.empty(n, dtype=torch.float64, device=gpu)
+    keep = [torch.from_numpy(np.ascontiguousarray(p)).to(gpu) if np.ndim(p) else p for p in params]
+    ops = (Operand * (1 + len(params)))()
+    ops[0].ptr, ops[0].div, ops[0].mod, ops[0].dtype = xt.data_ptr(), 1, n, F64
+    for j, p in enumerate(keep, start=1):
+        if isinstance(p, float):
+            ops[j].ptr, ops[j].scalar, ops[j].div, ops[j].mod, ops[j].dtype = None, p, 1, 1, F64
+        else:
+            ops[j].ptr, ops[j].scalar, ops[j].div, ops[j].mod, ops[j].dtype = p.data_ptr(), 0.0, 1, P, F64
+    at = lambda k: ctypes.cast(ctypes.byref(ops, k * ctypes.sizeof(Operand)), ctypes.POINTER(Operand))
+    _lib.check(_lib.lib().m355_elemwise(DIST[name], FN[fn], F64, n, at(0), len(params), at(1), out.data_ptr(),
+                                        torch.cuda.current_stream(gpu).cuda_stream))
+    flat = out.cpu().numpy()
+    assert np.array_equal(flat[: rows * P].reshape(rows, P), big, equal_nan=True)
+    tail_params = [np.asarray(p)[:tail] if np.ndim(p) else p for p in params]
+    assert np.array_equal(flat[rows * P:], getattr(m, fn)(x[rows * P:], *tail_params), equal_nan=True)
