@@ -129,6 +129,11 @@ template <class T, class = void> struct has_sum_acc : std::false_type {};
 template <class T> struct has_sum_acc<T, std::void_t<typename T::SumAcc>> : std::true_type {};
 constexpr int kRenormEvery = 64;  // tiles (4 elements per thread each) between LogProd renormalisations
 
+// Dist<D>::logpdf_f32 / f32_ok: a float32-arithmetic logpdf body for float32 data (k_scalar_f32), valid for the
+// parameters f32_ok accepts.
+template <class T, class = void> struct has_f32_body : std::false_type {};
+template <class T> struct has_f32_body<T, std::void_t<decltype(&T::logpdf_f32)>> : std::true_type {};
+
 template <int D, int FN, bool REDUCE, int IO>
 M355_DEV void scalar_body(const void* __restrict__ x, int xdt, void* __restrict__ out, int odt, long long n,
                           const typename Dist<D>::K& k, double* __restrict__ partials) {
@@ -136,6 +141,28 @@ M355_DEV void scalar_body(const void* __restrict__ x, int xdt, void* __restrict_
   if constexpr (uses_log_table<DD>::value) log_table_init();
   const long long ntiles = n / kTile;
   double acc = 0.0;
+  if constexpr (!REDUCE && IO == 2 && FN == M355_LOGPDF && has_f32_body<DD>::value) {
+    if (DD::f32_ok(k)) {  // uniform: parameters are kernel arguments
+      const float* xf = static_cast<const float*>(x);
+      float* of = static_cast<float*>(out);
+      for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const long long base = tile * kTile + threadIdx.x * kVec;
+        f2_t v[kUnroll];
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) v[u] = __builtin_nontemporal_load(reinterpret_cast<const f2_t*>(xf + base + u * (kBlock * kVec)));
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) {
+          f2_t r;
+          r.x = DD::logpdf_f32(v[u].x, k);
+          r.y = DD::logpdf_f32(v[u].y, k);
+          __builtin_nontemporal_store(r, reinterpret_cast<f2_t*>(of + base + u * (kBlock * kVec)));
+        }
+      }
+      for (long long i = ntiles * kTile + (long long)blockIdx.x * kBlock + threadIdx.x; i < n; i += (long long)gridDim.x * kBlock)
+        of[i] = DD::logpdf_f32(xf[i], k);
+      return;
+    }
+  }
   if constexpr (REDUCE && FN == M355_LOGPDF && has_sum_acc<DD>::value) {
     if (DD::sum_ok(k)) {  // uniform: parameters are kernel arguments
       typename DD::SumAcc s;

@@ -477,3 +477,30 @@ def test_colbinned_kernel_equals_periodic_kernel(gpu, name, fn, P):
     assert np.array_equal(flat[: rows * P].reshape(rows, P), big, equal_nan=True)
     tail_params = [np.asarray(p)[:tail] if np.ndim(p) else p for p in params]
     assert np.array_equal(flat[rows * P:], getattr(m, fn)(x[rows * P:], *tail_params), equal_nan=True)
+
+
+def test_float32_arithmetic_bodies(gpu):
+    """beta.logpdf on float32 data takes its two logarithms in float32 while the parameters are inside
+    Dist<beta>::f32_ok (|alpha - 1|, |beta - 1| <= 8, |betaln| <= 12) and the float64 body outside: both within the
+    float32 bar 1e-5 * max(1, |b|) of the oracle on the same float32 inputs, over the parameter box and at the edges
+    (0, 1, out of support, denormal and near-1 inputs, NaN)."""
+    from distributions_amd import beta
+
+    rng = np.random.default_rng(61)
+    n = 300_001
+    worst = 0.0
+    for a, b in [(2.0, 5.0), (0.1, 0.1), (0.5, 3.0), (1.0, 1.0), (9.0, 9.0), (9.0, 0.2), (1.0, 9.0), (4.5, 8.9), (0.11, 9.0),
+                 (100.0, 100.0), (30.0, 2.0)]:  # the last two are outside the box: float64 body
+        x = rng.beta(min(a, 20.0), min(b, 20.0), n).astype(np.float32)
+        x[:12] = [0.0, 1.0, -0.5, 1.5, np.nan, 1e-40, 1.2e-38, 1 - 6e-8, 0.5, 6e-8, 1e-30, 0.999]
+        x[12:2000] = np.exp(rng.uniform(-87, 0, 1988)).astype(np.float32)  # the whole float32 range of log x
+        got = beta.logpdf(x, np.float32(a), np.float32(b))
+        assert got.dtype == np.float32
+        with np.errstate(all="ignore"):
+            exp = R.beta_logpdf(x.astype(np.float64), float(np.float32(a)), float(np.float32(b)))
+        ok = H.close(got.astype(np.float64), exp, 1e-5)
+        assert np.all(ok), (a, b, x[~ok][:5], got[~ok][:5], exp[~ok][:5])
+        with np.errstate(all="ignore"):
+            fin = np.isfinite(exp)
+            worst = max(worst, float(np.max(np.abs(got[fin] - exp[fin]) / np.maximum(1.0, np.abs(exp[fin])))))
+    assert worst <= 1e-5
