@@ -19,8 +19,11 @@ M355_DEV double erfcinv_(double x) { return kNaN; }  // device libm only; not ho
 // reference iterates the whole batch until every element has converged; a converged element keeps x_prev,
 // which makes it converge again in every later iteration, so a per-lane loop with early exit gives the same
 // values.  A NaN iterate (NaN q, or a NaN cdf) stays NaN.
+#ifndef M355_FIND_PPF_ATTR
+#define M355_FIND_PPF_ATTR M355_DEV_HEAVY  // tools/findppf_probe.hip builds the inlined variant for comparison
+#endif
 template <class CDF, class PDF>
-M355_DEV_HEAVY double find_ppf(double q, double x0, double lower, double upper, CDF cdf, PDF pdf) {
+M355_FIND_PPF_ATTR double find_ppf(double q, double x0, double lower, double upper, CDF cdf, PDF pdf) {
   double x = x0;
   for (int it = 0; it < 100; ++it) {
     const double c = cdf(x);

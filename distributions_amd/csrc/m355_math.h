@@ -119,7 +119,7 @@ M355_HD double flog_pos(double x) {
 
 // Keeps a polynomial coefficient in a scalar register pair: without this the compiler
 // rematerialises every 64-bit literal with two v_mov_b32 per use (7 fp64-op equivalents per log).
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(M355_NO_SCONST)  // (M355_NO_SCONST: tools/findppf_probe.hip's A/B build)
 M355_DEV double sconst(double v) {
   asm("" : "+s"(v));
   return v;

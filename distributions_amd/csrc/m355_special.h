@@ -91,7 +91,11 @@ M355_HD_HEAVY double erfcx_huge(double a) { return 0.56418958354775628695 / a; }
 M355_HD double erfcx_pos(double a) {
   // beyond 2^500 (and for inf / NaN) erfcx(a) = 1 / (a sqrt(pi)) to the last bit: an out-of-line call under a
   // wave-rare branch, so that its division is not evaluated (as a select would) for every lane
+#if defined(M355_PROBE_NO_CALL)  // tools/findppf_probe.hip A/B: the rare path inline instead of a call
+  if (__builtin_expect(!(a < 0x1p500), 0)) return 0.56418958354775628695 / a;
+#else
   if (__builtin_expect(!(a < 0x1p500), 0)) return erfcx_huge(a);
+#endif
   const double r = rcp(a + 4.0);
   const double t = (a - 4.0) * r;
   double p = sconst(kErfcxP[kErfcxP_deg]);
