@@ -75,13 +75,35 @@ def mv_logpdf(kind: int, x, mu, cov, nu: float = 0.0):
             else:
                 cov_c, cdiv, cmod = cov.reshape(ncov, d, d).contiguous(), pl.div, pl.mod
         out = torch.empty(n, dtype=torch.float64, device=device)
+        quirk = onedim and batch != (1,) and n > 0
+        at_mean = torch.empty(n, dtype=torch.float64, device=device) if quirk else None
         if n:
             ws_bytes = int(L.m355_mvn_workspace_bytes(d, ncov))
             ws = torch.empty(ws_bytes, dtype=torch.uint8, device=device)
             stream = torch.cuda.current_stream(device).cuda_stream
             _lib.check(L.m355_mvn_logpdf(kind, n, d, xe.data_ptr(), mu_c.data_ptr(), mu_stride, cov_c.data_ptr(), ncov,
                                          cdiv, cmod, float(nu), out.data_ptr(), ws.data_ptr(), ws_bytes, stream))
+            if quirk:
+                # logpdf at delta = 0 (value = mu): the part of the result that does not depend on quaddist
+                mu_e = mu.expand(batch + (d,)).contiguous()
+                _lib.check(L.m355_mvn_logpdf(kind, n, d, mu_e.data_ptr(), mu_e.data_ptr(), d, cov_c.data_ptr(), ncov,
+                                             cdiv, cmod, float(nu), at_mean.data_ptr(), ws.data_ptr(), ws_bytes, stream))
     out = out.reshape(batch)
+    if quirk:
+        # mvnormal.py:34-35 returns quaddist[0] for a 1-d value: with batched mu / cov that is the quadratic form of
+        # the FIRST entry along the leading batch axis, which then broadcasts against every entry's logdet (and nu
+        # terms).  Reproduced as the reference computes it: result_b = logpdf_b(value = mu_b) + the quaddist-dependent
+        # part of entry 0 (for both kinds that part is logpdf - logpdf(value = mu)).
+        at_mean = at_mean.reshape(batch)
+        out = at_mean + (out[0] - at_mean[0])
+        # shape of the reference's result: logdet (cov's batch axes) against quaddist[0] (the batch without its
+        # leading axis); along the other axes `out` is constant
+        tshape = tuple(np.broadcast_shapes(cov_batch, batch[1:]))
+        lead = len(batch) - len(tshape)
+        out = out[(0,) * lead]
+        for ax, (td, bd) in enumerate(zip(tshape, batch[lead:])):
+            if td == 1 and bd != 1:
+                out = out.narrow(ax, 0, 1)
     if onedim and batch == (1,):
         out = out[0]  # mvnormal.py:34-35: a 1-d value is one observation and gives a 0-d result
     return out if want_torch else out.cpu().numpy()

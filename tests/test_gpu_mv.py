@@ -128,3 +128,27 @@ def test_matrixnormal_batched(gpu):
     Mu = rng.normal(size=(m, n))
     X = rng.normal(size=(B, m, n))
     assert np.all(H.close(matrixnormal.logpdf(X, Mu, U, V), R.matrixnormal_logpdf(X, Mu, U, V)))
+
+
+def test_one_dim_value_against_batched_parameters(gpu):
+    """mvnormal.py:34-35: a 1-d value returns quaddist[0]; with batched mu / cov that is the quadratic form of the
+    first batch entry broadcast against every entry's logdet -- the reference's behaviour, reproduced (the oracle
+    restates it line by line)."""
+    from distributions_amd import mvnormal, mvstudentt
+
+    rng = np.random.default_rng(77)
+    d, B = 5, 7
+    A = rng.normal(size=(B, d, d))
+    cov = A @ np.swapaxes(A, 1, 2) / d + np.eye(d)
+    mu = rng.normal(size=(B, d))
+    x = rng.normal(size=d)
+    for m_, c_ in ((mu[0], cov), (mu, cov[0]), (mu, cov)):
+        got = mvnormal.logpdf(x, m_, c_)
+        exp = R.mvnormal_logpdf(x, m_, c_)
+        assert got.shape == exp.shape == ((B,) if np.ndim(c_) == 3 else ())  # logdet's shape against quaddist[0]'s
+        assert np.all(H.close(got, exp)), (got, exp)
+        got = mvstudentt.logpdf(x, 4.5, m_, c_)
+        assert np.all(H.close(got, R.mvstudentt_logpdf(x, 4.5, m_, c_)))
+    cov2 = np.stack([cov[:6].reshape(2, 3, d, d)])[0]
+    got = mvnormal.logpdf(x, mu[0], cov2)
+    assert got.shape == (2, 3) and np.all(H.close(got, R.mvnormal_logpdf(x, mu[0], cov2)))
