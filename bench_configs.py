@@ -97,6 +97,25 @@ def periodic_special(torch, xs, q, out, rows):
         at = lambda k: ctypes.cast(ctypes.byref(ops, k * ctypes.sizeof(Operand)), ctypes.POINTER(Operand))
         _lib.check(L.m355_elemwise(DIST[name], FN[fn], F64, n, at(0), len(params), at(1), out.data_ptr(), stream))
 
+    sums = torch.zeros(1, dtype=torch.float64, device=dev)
+    ws = torch.empty(int(L.m355_sumlogp_workspace_bytes()), dtype=torch.uint8, device=dev)
+
+    def call_sum(name, params):
+        ops = (Operand * (1 + len(params)))()
+        ops[0].ptr, ops[0].div, ops[0].mod, ops[0].dtype = xs[name].data_ptr(), 1, n, F64
+        for j, p in enumerate(params, start=1):
+            if isinstance(p, float):
+                ops[j].ptr, ops[j].scalar, ops[j].div, ops[j].mod, ops[j].dtype = None, p, 1, 1, F64
+            else:
+                ops[j].ptr, ops[j].scalar, ops[j].div, ops[j].mod, ops[j].dtype = p.data_ptr(), 0.0, 1, P, F64
+        at = lambda k: ctypes.cast(ctypes.byref(ops, k * ctypes.sizeof(Operand)), ctypes.POINTER(Operand))
+        _lib.check(L.m355_sumlogp(DIST[name], FN["logpdf"], n, at(0), len(params), at(1), sums.data_ptr(), ws.data_ptr(),
+                                  ws.numel(), stream))
+
+    for name, params in cases.items():
+        ms = timed(torch, lambda: call_sum(name, params), reps=5)
+        print(json.dumps({"config": 2, "fn": f"{name}.sum_logpdf", "n": n, "layout": "params (1024,) row-periodic", "ms": ms,
+                          "evals_per_s": n / (ms * 1e-3), "GB_per_s_algorithmic": 8.0 * n / (ms * 1e-3) / 1e9}), flush=True)
     for name, params in cases.items():
         for fn in ("logpdf", "logcdf", "ppf"):
             src = q if fn == "ppf" else xs[name]

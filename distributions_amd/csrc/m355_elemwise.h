@@ -247,6 +247,12 @@ __global__ __launch_bounds__(kBlock) void k_periodic(const void* __restrict__ x,
   using K = typename DD::K;
   constexpr int NK = sizeof(K) / sizeof(double);
   extern __shared__ double lds[];  // [NK][P]
+  constexpr bool kProduct = REDUCE && FN == M355_LOGPDF && has_sum_acc<DD>::value;
+  __shared__ int all_sum_ok;
+  if constexpr (kProduct) {
+    if (threadIdx.x == 0) all_sum_ok = 1;
+    __syncthreads();
+  }
   if constexpr (uses_log_table<DD>::value) log_table_init();
   for (unsigned j = threadIdx.x; j < P; j += kBlock) {
     double pp[kMaxParams];
@@ -256,6 +262,9 @@ __global__ __launch_bounds__(kBlock) void k_periodic(const void* __restrict__ x,
     const double* kd = reinterpret_cast<const double*>(&k);
 #pragma unroll
     for (int f = 0; f < NK; ++f) lds[f * P + j] = kd[f];
+    if constexpr (kProduct) {
+      if (!DD::sum_ok(k)) all_sum_ok = 0;  // (every writer stores the same value)
+    }
   }
   __syncthreads();
   auto fetch = [&](unsigned idx) {
@@ -271,6 +280,54 @@ __global__ __launch_bounds__(kBlock) void k_periodic(const void* __restrict__ x,
   const unsigned tile_step = (unsigned)(((unsigned long long)gridDim.x * kTile) % P);
   const unsigned u_step = (unsigned)((kBlock * kVec) % P);
   double acc = 0.0;
+  if constexpr (kProduct) {
+    // Sum-logp as a product with row-periodic parameters: the launcher makes gridDim.x * kTile a multiple of P where it
+    // can, so a thread meets the same kUnroll * kVec columns in every tile it takes and keeps one product-form
+    // accumulator (Dist<D>::SumAcc) per column; the logarithms are taken once per thread and column at the end.
+    if (tile_step == 0 && all_sum_ok) {
+      typename DD::SumAcc sa[kUnroll][kVec];
+      K kc[kUnroll][kVec];
+      {
+        unsigned idx = idx0;
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) {
+          unsigned idx1 = idx + 1;
+          idx1 = idx1 >= P ? idx1 - P : idx1;
+          kc[u][0] = fetch(idx);
+          kc[u][1] = fetch(idx1);
+          idx += u_step;
+          idx = idx >= P ? idx - P : idx;
+        }
+      }
+      int since = 0;
+      for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const long long base = tile * kTile + threadIdx.x * kVec;
+        double v[kUnroll][kVec];
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) load2<IO>(x, xdt, base + u * (kBlock * kVec), v[u][0], v[u][1]);
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) {
+          DD::sum_add(sa[u][0], v[u][0], kc[u][0]);
+          DD::sum_add(sa[u][1], v[u][1], kc[u][1]);
+        }
+        if (++since == 4 * kRenormEvery) {  // one element per accumulator and tile: renormalise every 256 elements
+          since = 0;
+#pragma unroll
+          for (int u = 0; u < kUnroll; ++u) {
+            DD::sum_renorm(sa[u][0]);
+            DD::sum_renorm(sa[u][1]);
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < kUnroll; ++u) acc += DD::sum_finish(sa[u][0], kc[u][0]) + DD::sum_finish(sa[u][1], kc[u][1]);
+      for (long long i = ntiles * kTile + (long long)blockIdx.x * kBlock + threadIdx.x; i < n; i += (long long)gridDim.x * kBlock)
+        acc += DD::template eval<FN>(load1(x, xdt, i), fetch((unsigned)((unsigned long long)i % P)));
+      acc = block_reduce_sum(acc);
+      if (threadIdx.x == 0) partials[blockIdx.x] = acc;
+      return;
+    }
+  }
   for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const long long base = tile * kTile + threadIdx.x * kVec;
     double v[kUnroll][kVec];
@@ -722,6 +779,14 @@ template <int D, int FN, bool REDUCE> int launch_fn(const LaunchArgs& a) {
       c = 2 * 256 * per_cu < c ? 2 * 256 * per_cu : c;
     }
     blocks = (int)(tiles < 1 ? 1 : (tiles > c ? c : tiles));
+    if (REDUCE && !all_scalar) {
+      // k_periodic's product-form sum needs gridDim.x * kTile to be a multiple of P (a thread then keeps its columns):
+      // round the grid down to a multiple of P / gcd(P, kTile) where that leaves a grid at all
+      unsigned long long a_ = P, b_ = (unsigned long long)kTile;
+      while (b_) { const unsigned long long t_ = a_ % b_; a_ = b_; b_ = t_; }
+      const long long unit = (long long)(P / a_);
+      if (unit <= blocks) blocks = (int)((blocks / unit) * unit);
+    }
   } else {
     const long long want = (n + kBlock - 1) / kBlock;
     blocks = (int)(want < 1 ? 1 : (want > cap ? cap : want));

@@ -504,3 +504,38 @@ def test_float32_arithmetic_bodies(gpu):
             fin = np.isfinite(exp)
             worst = max(worst, float(np.max(np.abs(got[fin] - exp[fin]) / np.maximum(1.0, np.abs(exp[fin])))))
     assert worst <= 1e-5
+
+
+@pytest.mark.parametrize("P", [1024, 1000, 37, 8])
+def test_sumlogp_periodic_product_form(gpu, P):
+    """Fused sum-logp with row-periodic parameters: k_periodic keeps one product-form accumulator per column when the
+    grid makes a thread's columns fixed (gridDim * 1024 a multiple of P) and every column's coefficients are within
+    the product form's limit; totals against math.fsum of the oracle's terms (1e-12 * sum |term|), with exceptional
+    elements (0, out of support, inf, NaN) and with one column above the limit (plain summation for the launch)."""
+    from distributions_amd import beta, gamma, studentt
+
+    rng = np.random.default_rng(71)
+    rows = 3_000_000 // P + 3
+    for m, name, draw, params in (
+        (gamma, "gamma", lambda: rng.gamma(2.5, 1.0, (rows, P)), (rng.uniform(0.5, 9.0, P), rng.uniform(0.3, 3.0, P))),
+        (beta, "beta", lambda: rng.beta(2, 5, (rows, P)), (rng.uniform(0.5, 9.0, P), 4.0)),
+        (studentt, "studentt", lambda: 2 * rng.standard_t(5, (rows, P)), (rng.uniform(2.0, 30.0, P), 0.1, rng.uniform(0.5, 2.0, P))),
+    ):
+        x = draw()
+        for extra in ([], [0.0], [-1.0, np.inf], [np.nan]):
+            xx = x.copy()
+            for j, e in enumerate(extra):
+                xx[(j + 1) * 17, (j * 5) % P] = e
+            with np.errstate(all="ignore"):
+                terms = R.TABLE[f"{name}_logpdf"](xx, *params)
+                exp = float(np.sum(terms))
+            got = m.sum_logpdf(xx, *params)
+            if math.isfinite(exp):
+                assert abs(got - math.fsum(terms.ravel())) <= 1e-12 * float(np.abs(terms).sum()), (name, P, extra, got, exp)
+            else:
+                assert (math.isnan(exp) and math.isnan(got)) or got == exp, (name, P, extra, got, exp)
+        if name == "gamma":  # one column beyond kSumAccMaxCoef: the launch falls back to summing logpdf()
+            a2 = params[0].copy()
+            a2[P // 2] = 5000.0
+            terms = R.gamma_logpdf(x, a2, params[1])
+            assert abs(m.sum_logpdf(x, a2, params[1]) - math.fsum(terms.ravel())) <= 1e-12 * float(np.abs(terms).sum())
