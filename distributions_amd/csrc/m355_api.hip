@@ -183,6 +183,12 @@ int m355_sumlogp(int dist, int fn, int64_t n, const m355_operand* x, int nparams
   a.partials = static_cast<double*>(workspace);
   a.nblocks_out = &nblocks;
   a.stream = s;
+  // what the workspace holds beyond the partials serves as scratch for a table of derived constants (row-periodic
+  // parameters, k_periodic_prod); the 32 KiB array of m355_sumlogp_static has none and keeps the LDS-table kernel
+  if (workspace_bytes > sumlogp_workspace_min_bytes()) {
+    a.table = static_cast<double*>(workspace) + m355::kMaxReduceBlocks;
+    a.table_doubles = (long long)((workspace_bytes - sumlogp_workspace_min_bytes()) / sizeof(double));
+  }
   const int rc2 = check_launch(dispatch(dist, a));
   if (rc2 != M355_OK) return rc2;
   hipLaunchKernelGGL(k_final, dim3(1), dim3(m355::kBlock), 0, s, static_cast<const double*>(workspace), nblocks,

@@ -48,6 +48,8 @@ struct LaunchArgs {
   void* out;         // elementwise result (unused with partials)
   double* partials;  // non-null: reduce, one double per workgroup
   int* nblocks_out;  // receives the number of partials written
+  double* table = nullptr;      // reduce only: device scratch for a table of derived constants (k_periodic_prod), or null
+  long long table_doubles = 0;  // its capacity
   hipStream_t stream;
 };
 
@@ -361,6 +363,99 @@ __global__ __launch_bounds__(kBlock) void k_periodic(const void* __restrict__ x,
     acc = block_reduce_sum(acc);
     if (threadIdx.x == 0) partials[blockIdx.x] = acc;
   }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Sum-logp as a product with row-periodic parameters, table-free variant.  k_periodic keeps every workgroup's P derived
+// constant sets in LDS (48 KiB for beta at P = 1024: two or three workgroups per CU, too few wavefronts to keep the HBM
+// stream busy, and every workgroup repeats the P lgamma / log derivations).  When the caller's workspace has room,
+// k_derive_table writes the table once to device memory ([field][P]) and k_periodic_prod streams x with no LDS at all:
+// the launcher makes gridDim.x * kTile a multiple of P, so a thread meets the same kUnroll * kVec columns in every tile,
+// reads their constants once (L2) and keeps one Dist<D>::SumAcc per column.  A column whose coefficients exceed the
+// product form's limit (sum_ok) takes logpdf() per element, for that thread's accumulator only.
+template <int D>
+__global__ __launch_bounds__(kBlock) void k_derive_table(PeriodicParams pa, unsigned P, double* __restrict__ table) {
+  using DD = Dist<D>;
+  using K = typename DD::K;
+  constexpr int NK = sizeof(K) / sizeof(double);
+  const unsigned j = blockIdx.x * kBlock + threadIdx.x;
+  if (j >= P) return;
+  double pp[kMaxParams];
+#pragma unroll
+  for (int q = 0; q < kMaxParams; ++q) pp[q] = (q < DD::NP && pa.ptr[q]) ? pa.ptr[q][j] : pa.scalar[q];
+  const K k = DD::derive(pp);
+  const double* kd = reinterpret_cast<const double*>(&k);
+#pragma unroll
+  for (int f = 0; f < NK; ++f) table[(size_t)f * P + j] = kd[f];
+}
+
+template <int D, bool F64IO>
+__global__ __launch_bounds__(kBlock) void k_periodic_prod(const void* __restrict__ x, int xdt, long long n, unsigned P,
+                                                          const double* __restrict__ table, double* __restrict__ partials) {
+  constexpr int IO = F64IO ? 1 : 0;
+  using DD = Dist<D>;
+  using K = typename DD::K;
+  constexpr int NK = sizeof(K) / sizeof(double);
+  if constexpr (uses_log_table<DD>::value) log_table_init();
+  auto fetch = [&](unsigned idx) {
+    K k;
+    double* kd = reinterpret_cast<double*>(&k);
+#pragma unroll
+    for (int f = 0; f < NK; ++f) kd[f] = table[(size_t)f * P + idx];
+    return k;
+  };
+  const long long ntiles = n / kTile;
+  typename DD::SumAcc sa[kUnroll][kVec];
+  K kc[kUnroll][kVec];
+  bool ok[kUnroll][kVec];
+  {
+    unsigned idx = (unsigned)(((unsigned long long)blockIdx.x * kTile + threadIdx.x * kVec) % P);
+    const unsigned u_step = (unsigned)((kBlock * kVec) % P);
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) {
+      unsigned idx1 = idx + 1;
+      idx1 = idx1 >= P ? idx1 - P : idx1;
+      kc[u][0] = fetch(idx);
+      kc[u][1] = fetch(idx1);
+      ok[u][0] = DD::sum_ok(kc[u][0]);
+      ok[u][1] = DD::sum_ok(kc[u][1]);
+      idx += u_step;
+      idx = idx >= P ? idx - P : idx;
+    }
+  }
+  double acc = 0.0;
+  int since = 0;
+  for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const long long base = tile * kTile + threadIdx.x * kVec;
+    double v[kUnroll][kVec];
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) load2<IO>(x, xdt, base + u * (kBlock * kVec), v[u][0], v[u][1]);
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) {
+#pragma unroll
+      for (int w = 0; w < kVec; ++w) {
+        if (ok[u][w]) DD::sum_add(sa[u][w], v[u][w], kc[u][w]);
+        else acc += DD::template eval<M355_LOGPDF>(v[u][w], kc[u][w]);
+      }
+    }
+    if (++since == 4 * kRenormEvery) {  // one element per accumulator and tile: renormalise every 256 elements
+      since = 0;
+#pragma unroll
+      for (int u = 0; u < kUnroll; ++u) {
+        DD::sum_renorm(sa[u][0]);
+        DD::sum_renorm(sa[u][1]);
+      }
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < kUnroll; ++u) {
+#pragma unroll
+    for (int w = 0; w < kVec; ++w) acc += ok[u][w] ? DD::sum_finish(sa[u][w], kc[u][w]) : 0.0;
+  }
+  for (long long i = ntiles * kTile + (long long)blockIdx.x * kBlock + threadIdx.x; i < n; i += (long long)gridDim.x * kBlock)
+    acc += DD::template eval<M355_LOGPDF>(load1(x, xdt, i), fetch((unsigned)((unsigned long long)i % P)));
+  acc = block_reduce_sum(acc);
+  if (threadIdx.x == 0) partials[blockIdx.x] = acc;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -829,6 +924,28 @@ template <int D, int FN, bool REDUCE> int launch_fn(const LaunchArgs& a) {
     for (int q = 0; q < kMaxParams; ++q) {
       pa.ptr[q] = (q < DD::NP) ? static_cast<const double*>(a.p[q].ptr) : nullptr;
       pa.scalar[q] = a.p[q].scalar;
+    }
+    if constexpr (REDUCE && FN == M355_LOGPDF && has_sum_acc<DD>::value) {
+      // table-free product-form kernel when the workspace can hold the derived constants and the grid can be a
+      // multiple of P / gcd(P, kTile)
+      constexpr long long NK = sizeof(typename DD::K) / sizeof(double);
+      unsigned long long a_ = P, b_ = (unsigned long long)kTile;
+      while (b_) { const unsigned long long t_ = a_ % b_; a_ = b_; b_ = t_; }
+      const long long unit = (long long)(P / a_);
+      long long pb = tiles > kMaxReduceBlocks ? kMaxReduceBlocks : tiles;
+      pb = (pb / unit) * unit;
+      if (!all_scalar && a.table != nullptr && (long long)P * NK <= a.table_doubles && pb >= 1) {
+        hipLaunchKernelGGL((k_derive_table<D>), dim3((unsigned)((P + kBlock - 1) / kBlock)), dim3(kBlock), 0, a.stream, pa,
+                           (unsigned)P, a.table);
+        if (a.nblocks_out) *a.nblocks_out = (int)pb;
+        if (f64io)
+          hipLaunchKernelGGL((k_periodic_prod<D, true>), dim3((unsigned)pb), dim3(kBlock), 0, a.stream, a.x.ptr, a.x.dtype, n,
+                             (unsigned)P, a.table, a.partials);
+        else
+          hipLaunchKernelGGL((k_periodic_prod<D, false>), dim3((unsigned)pb), dim3(kBlock), 0, a.stream, a.x.ptr, a.x.dtype, n,
+                             (unsigned)P, a.table, a.partials);
+        return (int)hipGetLastError();
+      }
     }
     const void* xp = a.x.ptr;
     void* op = a.out;
