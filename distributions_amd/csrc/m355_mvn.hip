@@ -101,25 +101,46 @@ constexpr int kCholThreads = 256;
 // below 1e-12 (measured to cond(cov) = 1e10 against a long-double solve).  Larger d keeps substitution.
 constexpr int kFullInverseMaxNB = 4;
 
-__global__ __launch_bounds__(kCholThreads) void k_cholesky(const double* __restrict__ cov, int d,
-                                                            double* __restrict__ ws, double* __restrict__ frags) {
+// One observation with its own covariance (FUSED, one wavefront per matrix, d <= 64): after the factorisation the
+// forward substitution, the sum of squares and the epilogue run in the same workgroup from the factor in LDS, so a
+// matrix is read from HBM once and nothing but the result is written.
+struct FusedArgs {
+  const double* x;   // n x d
+  const double* mu;  // d (mu_stride 0) or n x d
+  long long mu_stride;
+  double* out;
+  int mode;          // 1: mvnormal logpdf, 2: mvstudentt logpdf
+  double nu, c0;
+};
+
+template <int THREADS, bool FUSED>
+__device__ __forceinline__ void cholesky_body(const double* __restrict__ cov, int d, double* __restrict__ ws,
+                                              double* __restrict__ frags, const FusedArgs& fa) {
+  constexpr int kCholThreads = THREADS;
   extern __shared__ double a[];  // dp x S (S odd) | 16x16 diagonal block + 16 reciprocals | NB x 16 x 16 inverses | dp reciprocals
   const int NB = nblk16(d);
   const int dp = 16 * NB, S = dp + 1;
   double* diag = a + (size_t)dp * S;
   double* inv = diag + 272;
-  double* rdiag = inv + (NB <= kFullInverseMaxNB ? NB * (NB + 1) / 2 : NB) * 256;
+  double* rdiag = inv + (FUSED ? 0 : (NB <= kFullInverseMaxNB ? NB * (NB + 1) / 2 : NB) * 256);
   const double* src = cov + (size_t)blockIdx.x * d * d;
-  double* dst = ws + (size_t)blockIdx.x * chol_stride(d);
+  double* dst = FUSED ? nullptr : ws + (size_t)blockIdx.x * chol_stride(d);
   const int t = threadIdx.x, wave = t >> 6;
   // 2-D thread layout for the global <-> LDS copies: CW columns x (256 / CW) rows per step
   const int cshift = dp <= 16 ? 4 : (dp <= 32 ? 5 : (dp <= 64 ? 6 : 7));
   const int ccol = t & ((1 << cshift) - 1), crow0 = t >> cshift, crstep = kCholThreads >> cshift;
   M355_TICK(0);
   if (ccol < dp) {
+    if constexpr (FUSED) {
+      // one wavefront, four of them per CU (LDS): the matrix load is pure HBM latency, so keep 32 row loads in flight
+#pragma unroll 32
+      for (int r = crow0; r < dp; r += crstep)
+        a[r * S + ccol] = (r < d && ccol < d) ? __builtin_nontemporal_load(src + r * d + ccol) : (r == ccol ? 1.0 : 0.0);
+    } else {
 #pragma unroll 8
-    for (int r = crow0; r < dp; r += crstep)
-      a[r * S + ccol] = (r < d && ccol < d) ? src[r * d + ccol] : (r == ccol ? 1.0 : 0.0);
+      for (int r = crow0; r < dp; r += crstep)
+        a[r * S + ccol] = (r < d && ccol < d) ? src[r * d + ccol] : (r == ccol ? 1.0 : 0.0);
+    }
   }
   __syncthreads();
   M355_TICK(1);
@@ -153,14 +174,17 @@ __global__ __launch_bounds__(kCholThreads) void k_cholesky(const double* __restr
       const int base = c0 & 63;
       const int r = (i & 63) - base;
       double rinv[16];
+      // right-looking inside the panel: as soon as column c is known every later column takes its update
+      // u[c2] -= l[c] L[16J+c2][c] (15 - c independent FMAs) instead of a chain of c dependent FMAs in front of every
+      // pivot.  The updates reach each u[c2] in the same order c = 0, 1, ... as in the left-looking form: bit-identical
+      // factors.  (Measured: no faster -- the panel is bound by the issue of its readlanes and FMAs, not by the chain.)
 #pragma unroll
       for (int c = 0; c < 16; ++c) {
-        double sacc = u[c];
-#pragma unroll
-        for (int cc = 0; cc < c; ++cc) sacc = __builtin_fma(-l[cc], readlane_d(l[cc], base + c), sacc);
         double piv;
-        sqrt_rsqrt(readlane_d(sacc, base + c), piv, rinv[c]);
-        l[c] = (r == c) ? piv : (r > c ? sacc * rinv[c] : 0.0);
+        sqrt_rsqrt(readlane_d(u[c], base + c), piv, rinv[c]);
+        l[c] = (r == c) ? piv : (r > c ? u[c] * rinv[c] : 0.0);
+#pragma unroll
+        for (int c2 = c + 1; c2 < 16; ++c2) u[c2] = __builtin_fma(-l[c], readlane_d(l[c], base + c2), u[c2]);
       }
       if (r >= 0 && r < 16) {
 #pragma unroll
@@ -194,6 +218,28 @@ __global__ __launch_bounds__(kCholThreads) void k_cholesky(const double* __restr
     M355_TICK(5 + 4 * J);
   }
   M355_TICK(40);
+  if constexpr (FUSED) {
+    // (one wavefront: lane = row)  logdet = 2 sum log diag; forward substitution by columns: y_k = acc_k / L_kk is
+    // broadcast from lane k, every later row takes acc_i -= y_k L_ik (one conflict-free LDS read per lane: odd stride)
+    double lg = (i < d) ? flog(ai[i]) : 0.0;  // log of a NaN diag -> NaN
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) lg += __shfl_xor(lg, o, 64);
+    const double logdet = 2.0 * lg;
+    const long long b = blockIdx.x;
+    double acc = (i < d) ? fa.x[b * d + i] - fa.mu[(fa.mu_stride ? b * fa.mu_stride : 0) + i] : 0.0;
+    double quad = 0.0;
+    for (int k = 0; k < d; ++k) {
+      const double yk = readlane_d(acc, k) * rdiag[k];
+      quad = __builtin_fma(yk, yk, quad);
+      acc = __builtin_fma(-yk, ai[k], acc);  // rows i <= k are finished: what happens to their acc is irrelevant
+    }
+    if (t == 0) {
+      double v = -0.5 * (fa.c0 + logdet + quad);  // mvnormal.py:82-83
+      if (fa.mode == 2) v = fa.c0 - 0.5 * (fa.nu + (double)d) * flog1p(quad / fa.nu) - 0.5 * logdet;  // mvstudentt.py:62-64
+      fa.out[b] = v;
+    }
+    return;
+  }
   if (ccol < d) {
 #pragma unroll 8
     for (int r = crow0; r < d; r += crstep) dst[r * d + ccol] = (ccol <= r) ? a[r * S + ccol] : 0.0;
@@ -206,7 +252,7 @@ __global__ __launch_bounds__(kCholThreads) void k_cholesky(const double* __restr
     for (int o = 32; o > 0; o >>= 1) lg += __shfl_down(lg, o, 64);
     if ((t & 63) == 0) diag[wave] = lg;
     __syncthreads();
-    if (t == 0) dst[(size_t)d * d + d] = 2.0 * (diag[0] + diag[1]);  // rows live in wavefronts 0 and 1 only
+    if (t == 0) dst[(size_t)d * d + d] = 2.0 * (diag[0] + (THREADS > 64 ? diag[1] : 0.0));  // rows live in wavefronts 0 and 1 only
   }
   M355_TICK(41);
   if (frags == nullptr) return;
@@ -269,6 +315,15 @@ __global__ __launch_bounds__(kCholThreads) void k_cholesky(const double* __restr
     }
   }
   M355_TICK(43);
+}
+
+__global__ __launch_bounds__(kCholThreads) void k_cholesky(const double* __restrict__ cov, int d,
+                                                            double* __restrict__ ws, double* __restrict__ frags) {
+  cholesky_body<kCholThreads, false>(cov, d, ws, frags, FusedArgs{});
+}
+// One wavefront per (covariance, observation) pair, d <= 64: factorisation, solve and epilogue fused.
+__global__ __launch_bounds__(64) void k_mvn_batched(const double* __restrict__ cov, int d, const FusedArgs fa) {
+  cholesky_body<64, true>(cov, d, nullptr, nullptr, fa);
 }
 
 struct SolveArgs {
@@ -569,6 +624,12 @@ int run_cholesky(const double* cov, long long ncov, int d, double* ws, double* f
   hipLaunchKernelGGL(m355::k_cholesky, dim3((unsigned)ncov), dim3(threads), lds, s, cov, d, ws, frags);
   return launched();
 }
+int run_batched(const double* cov, long long n, int d, const m355::FusedArgs& fa, hipStream_t s) {
+  const int dp = 16 * m355::nblk16(d);
+  const size_t lds = ((size_t)dp * (dp + 1) + 272 + dp) * sizeof(double);
+  hipLaunchKernelGGL(m355::k_mvn_batched, dim3((unsigned)n), dim3(64), lds, s, cov, d, fa);
+  return launched();
+}
 template <int NB, bool MU_ROWS> int launch_mfma(const m355::MfmaArgs& a, hipStream_t s) {
   constexpr bool REGF = NB <= m355::kFullInverseMaxNB;  // W = L^-1 blocks in registers (80 VGPRs at NB = 4)
   constexpr int T = 1;  // tiles per wavefront step
@@ -641,6 +702,13 @@ extern "C" int m355_mvn_logpdf(int kind, int64_t n, int d, const double* x, cons
   auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
   const bool mfma = ncov == 1 && al16(x) && (mu_stride == 0 || (mu_stride == d && al16(mu)));
   double* frags = mfma ? ws + chol_stride(d) : nullptr;
+  const double lognorm_n0 = (double)d * 1.8378770664093454836;
+  if (d <= 64 && ncov == n && cov_div == 1 && cov_mod == n && n > 1 && n <= 0x7fffffffLL) {
+    // one covariance per observation: fused factorisation + solve, one wavefront per pair, no factor written
+    const double lt = kind == 1 ? lgamma((nu + d) / 2.0) - lgamma(nu / 2.0) - 0.5 * d * log(nu * 3.14159265358979323846) : 0.0;
+    FusedArgs fa{x, mu, (long long)mu_stride, out, kind == 0 ? 1 : 2, nu, kind == 0 ? lognorm_n0 : lt};
+    return run_batched(cov, n, d, fa, s);
+  }
   int rc = run_cholesky(cov, ncov, d, ws, frags, s);
   if (rc != M355_OK) return rc;
   const double lognorm_n = (double)d * 1.8378770664093454836;  // k*log(2 pi)

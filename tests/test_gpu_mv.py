@@ -152,3 +152,29 @@ def test_one_dim_value_against_batched_parameters(gpu):
     cov2 = np.stack([cov[:6].reshape(2, 3, d, d)])[0]
     got = mvnormal.logpdf(x, mu[0], cov2)
     assert got.shape == (2, 3) and np.all(H.close(got, R.mvnormal_logpdf(x, mu[0], cov2)))
+
+
+@pytest.mark.parametrize("d", [64, 33, 7, 1])
+def test_one_covariance_per_observation_fused(gpu, d):
+    """SURVEY.md 8(d) config 4, variant B: cov carries the batch axis (mvnormal.py:27) -- one wavefront factors each
+    matrix and solves its observation in the same workgroup (k_mvn_batched).  1e-12 against the restatement, shared
+    and per-row means, both kinds; a non-positive-definite matrix gives NaN for its row only (quirk Q5)."""
+    from distributions_amd import mvnormal, mvstudentt
+
+    rng = np.random.default_rng(91 + d)
+    n = 1500
+    A = rng.normal(size=(n, d, d))
+    cov = A @ np.swapaxes(A, 1, 2) / d + np.eye(d)
+    mu = rng.normal(size=d)
+    mu_rows = rng.normal(size=(n, d))
+    X = rng.normal(size=(n, d)) * 1.5
+    for m_ in (mu, mu_rows):
+        got = mvnormal.logpdf(X, m_, cov)
+        assert got.shape == (n,)
+        assert np.all(H.close(got, R.mvnormal_logpdf(X, m_, cov)))
+        assert np.all(H.close(mvstudentt.logpdf(X, 6.5, m_, cov), R.mvstudentt_logpdf(X, 6.5, m_, cov)))
+    if d > 1:
+        bad = cov.copy()
+        bad[5] = -np.eye(d)
+        got = mvnormal.logpdf(X, mu, bad)
+        assert np.isnan(got[5]) and np.all(H.close(np.delete(got, 5), np.delete(R.mvnormal_logpdf(X, mu, cov), 5)))
