@@ -10,6 +10,7 @@
 // or BTRS (Hoermann 1993).  Rejection loops run per lane with a bounded attempt count.
 #pragma once
 #include "m355_dists4.h"
+#include "m355_sincoscoef.h"
 
 namespace m355 {
 
@@ -43,12 +44,13 @@ M355_HD Philox philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3,
   return p;
 }
 
-// Uniform in the open interval (0, 1) from two 32-bit words: 52 random bits k, u = (k + 1/2) 2^-52.  k + 1/2 needs
-// 53 significant bits, so it is exact and u lies in [2^-53, 1 - 2^-53] (with 53 random bits k + 1/2 would round to
-// 2^53 for the largest k and u would be exactly 1: log(1 - u) = -inf in the inverse-CDF samplers).
+// Uniform in the open interval (0, 1) from two 32-bit words: the 52 random bits k = (hi >> 12 : lo) become the mantissa
+// of a double in [1, 2), d = 1 + k 2^-52, and u = d - (1 - 2^-53) = (k + 1/2) 2^-52.  The difference has 53 significant
+// bits, so it is exact, and u lies in [2^-53, 1 - 2^-53]: neither log(u) nor log(1 - u) in the inverse-CDF samplers can
+// be infinite.  Two integer operations and one add (the int -> double conversions of both halves cost ten).
 M355_HD double u53(unsigned hi, unsigned lo) {
-  const unsigned long long k = ((unsigned long long)(hi >> 6) << 26) | (unsigned long long)(lo >> 6);
-  return ((double)k + 0.5) * 0x1.0p-52;
+  const unsigned long long bits = ((unsigned long long)(0x3ff00000u | (hi >> 12)) << 32) | (unsigned long long)lo;
+  return __builtin_bit_cast(double, bits) - (1.0 - 0x1.0p-53);
 }
 
 // Stream of uniform pairs for one element: pair j is Philox block (index, attempt = j, stream).
@@ -80,13 +82,25 @@ M355_DEV double fsqrt(double a) {
 #endif
 }
 
-M355_DEV void sincos_2pi(double u, double& s, double& c) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  ::sincospi(2.0 * u, &s, &c);
-#else
-  s = ::sin(2.0 * kPi * u);
-  c = ::cos(2.0 * kPi * u);
-#endif
+// sin(2 pi u), cos(2 pi u) for u in (0, 1): 4u = n + r exactly (n = rint(4u), |r| <= 1/2), sin / cos of pi r / 2 by two
+// degree-7 polynomials in r^2 (tools/gen_sincos_coeffs.py, 1.5e-16), quadrant by swaps and signs.  ~25 operations; the
+// device libm's sincospi, with its general argument reduction, was ~60 of the ~95 a normal draw cost.
+M355_HD void sincos_2pi(double u, double& s, double& c) {
+  const double t = 4.0 * u;
+  const double nf = __builtin_rint(t);
+  const double r = t - nf;
+  const double w = r * r;
+  // coefficients in scalar registers (sconst): as literals each one costs a v_mov_b64 per Horner step
+  double ps = sconst(kSinP[kSinP_deg]), pc = sconst(kCosP[kCosP_deg]);
+#pragma unroll
+  for (int k = kSinP_deg - 1; k >= 0; --k) ps = __builtin_fma(ps, w, sconst(kSinP[k]));
+#pragma unroll
+  for (int k = kCosP_deg - 1; k >= 0; --k) pc = __builtin_fma(pc, w, sconst(kCosP[k]));
+  const double sr = r * ps, cr = pc;
+  const int q = (int)nf;
+  const double s0 = (q & 1) ? cr : sr, c0 = (q & 1) ? sr : cr;
+  s = (q & 2) ? -s0 : s0;
+  c = ((q + 1) & 2) ? -c0 : c0;
 }
 
 // Two independent standard normals from one uniform pair (Box-Muller).

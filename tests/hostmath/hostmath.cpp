@@ -99,6 +99,10 @@ extern "C" void hm_log_tab(long n, const double* x, double* out) { for (long i =
 extern "C" void hm_log1p_stream(long n, const double* x, double* out) { for (long i = 0; i < n; ++i) out[i] = flog1p_stream(x[i]); }
 
 #include "../../distributions_amd/csrc/m355_rng.h"
+extern "C" void hm_sincos2pi(long n, const double* u, double* out) {  // out[2i] = sin, out[2i+1] = cos; n counts outputs / 2
+  for (long i = 0; i < n; ++i) sincos_2pi(u[i], out[2 * i], out[2 * i + 1]);
+}
+extern "C" double hm_u53(unsigned hi, unsigned lo) { return u53(hi, lo); }
 extern "C" void hm_philox(const unsigned* ctr, const unsigned* key, unsigned* out) {
   const Philox p = philox4x32_10(ctr[0], ctr[1], ctr[2], ctr[3], key[0], key[1]);
   for (int i = 0; i < 4; ++i) out[i] = p.c[i];
