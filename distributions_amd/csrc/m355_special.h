@@ -8,6 +8,7 @@
 #include "m355_logfact128.h"
 #include "m355_math.h"
 #include "m355_erfcoef.h"
+#include "m355_temmecoef.h"
 
 namespace m355 {
 
@@ -318,6 +319,50 @@ M355_DEV_HEAVY double gammaincc_series(double a, double x, double lga) {
   return t - exp_(a * logx - lga) * sum;
 }
 
+// Temme's uniform asymptotic expansion (DLMF 8.12.7-8; tools/gen_temme_coeffs.py) for a >= kTemmeMinA and
+// |x - a| <= kTemmeMaxSigma a -- the transition region, where the series and the continued fraction need O(sqrt(a))
+// terms (and more than kMaxIter of them beyond a ~ 1e8) and SciPy's gammainc / gammaincc take this same expansion:
+//   eta^2/2 = mu - log(1 + mu), mu = (x - a)/a;   y = a eta^2/2;   T = sum_k c_k(eta) a^-k
+//   x <  a:  P = exp(-y) [ erfcx(sqrt y)/2 - T / sqrt(2 pi a) ],  Q = 1 - P
+//   x >= a:  Q = exp(-y) [ erfcx(sqrt y)/2 + T / sqrt(2 pi a) ],  P = 1 - Q
+// One exponential, one erfcx, ~30-90 FMAs whatever a is; the terms c_k a^-k below 1e-17 are skipped (a >= 800: k <= 5,
+// a >= 7e4: k <= 2).  Returns Q when `upper`, else P.
+template <int N> M355_HD double temme_poly(const double (&c)[N], double eta) {
+  double p = sconst(c[N - 1]);
+#pragma unroll
+  for (int i = N - 2; i >= 0; --i) p = __builtin_fma(p, eta, sconst(c[i]));
+  return p;
+}
+M355_HD_HEAVY double gammainc_temme(double a, double x, bool upper) {
+  const double mu = fdiv(x - a, a);
+  const double phi = -log1pmx(mu);
+  const double y = a * phi;
+  const double eta = (x < a) ? -sqrt_(2.0 * phi) : sqrt_(2.0 * phi);
+  const double ia = 1.0 / a;
+  double t = 0.0;
+  if (a < 800.0) {
+    t = temme_poly(kTemmeC8, eta);
+    t = __builtin_fma(t, ia, temme_poly(kTemmeC7, eta));
+    t = __builtin_fma(t, ia, temme_poly(kTemmeC6, eta));
+  }
+  if (a < 7e4) {
+    t = __builtin_fma(t, ia, temme_poly(kTemmeC5, eta));
+    t = __builtin_fma(t, ia, temme_poly(kTemmeC4, eta));
+    t = __builtin_fma(t, ia, temme_poly(kTemmeC3, eta));
+  }
+  t = __builtin_fma(t, ia, temme_poly(kTemmeC2, eta));
+  t = __builtin_fma(t, ia, temme_poly(kTemmeC1, eta));
+  t = __builtin_fma(t, ia, temme_poly(kTemmeC0, eta));
+  const double s = t * sqrt_(ia * (0.5 / kPi));  // T / sqrt(2 pi a)
+  const double h = 0.5 * erfcx_pos(sqrt_(y));
+  const bool lower_small = x < a;
+  const double small = exp_(-y) * (lower_small ? h - s : h + s);
+  return (lower_small == upper) ? 1.0 - small : small;
+}
+M355_HD bool temme_region(double a, double x) {
+  return (a >= kTemmeMinA) & (__builtin_fabs(x - a) <= kTemmeMaxSigma * a) & (a < kInf);
+}
+
 // Regularised lower incomplete gamma P(a, x) (pt.gammainc).  lga = lgamma(a).
 M355_DEV double gammainc_q(double a, double x, double lga);
 M355_DEV double gammainc_p(double a, double x, double lga) {
@@ -326,6 +371,7 @@ M355_DEV double gammainc_p(double a, double x, double lga) {
   if (x == 0.0) return 0.0;
   if (a == kInf) return x == kInf ? kNaN : 0.0;
   if (x == kInf) return 1.0;
+  if (temme_region(a, x)) return gammainc_temme(a, x, false);
   if (x > 1.0 && x > a) return 1.0 - gammainc_q(a, x, lga);
   return gammainc_series(a, x, lga);
 }
@@ -337,6 +383,7 @@ M355_DEV double gammainc_q(double a, double x, double lga) {
   if (x == 0.0) return 1.0;
   if (a == kInf) return x == kInf ? kNaN : 1.0;
   if (x == kInf) return 0.0;
+  if (temme_region(a, x)) return gammainc_temme(a, x, true);
   if (x > 1.1) {
     return (x < a) ? 1.0 - gammainc_series(a, x, lga) : gammaincc_cf(a, x, lga);
   }
@@ -375,6 +422,14 @@ M355_DEV double gammaincinv_p(double a, double p, double lga) {
   if (p == 1.0) return kInf;
   const bool upper = p > 0.5;
   const double q = 1.0 - p;  // exact for p in [0.5, 1]
+  const double isa = fdiv(1.0, sqrt_(a));
+  // The Halley step's cubic error law holds in units of the distribution's width, x / sqrt(a) for a > 1: a step of
+  // u widths leaves ~u^3 widths, i.e. u^3 / sqrt(a) of x.  The threshold on the step relative to x scales accordingly
+  // (at a = 2e10 a 2e-6 x step is 0.28 widths and would leave 1e-7 x).
+  const double halley_tol = a > 1.0 ? kRootStepHalley * isa : kRootStepHalley;
+  // Likewise the Newton branches: u widths leave ~u^2 widths = u^2 / sqrt(a) of x, so the step bound goes as a^(-1/4)
+  // (measured at a = 2e10 with the fixed 2e-9: roots 1.4e-13 off).
+  const double newton_tol = a > 1.0 ? kRootStep * sqrt_(isa) : kRootStep;
   // --- initial guess
   double x;
   {
@@ -391,7 +446,7 @@ M355_DEV double gammaincinv_p(double a, double p, double lga) {
     } else {
       // Wilson-Hilferty
       const double z = norm_quantile_guess(p);
-      const double w = 1.0 - fdiv(1.0, 9.0 * a) + z * fdiv(1.0, 3.0 * sqrt_(a));
+      const double w = 1.0 - fdiv(1.0, 9.0 * a) + z * (isa * (1.0 / 3.0));
       x = a * w * w * w;
       if (!(w > 0.0) || x < 1e-3 * a) x = xs;
       if (upper) {
@@ -433,7 +488,7 @@ M355_DEV double gammaincinv_p(double a, double p, double lga) {
         xn = x - x * (halley ? fdiv(dx_rel, den) : dx_rel);
       }
     }
-    if (xn > 0.0 && __builtin_fabs(xn - x) <= (halley ? kRootStepHalley : kRootStep) * x) {  // converged (also when xn rounds onto a bracket end)
+    if (xn > 0.0 && __builtin_fabs(xn - x) <= (halley ? halley_tol : newton_tol) * x) {  // converged (also when xn rounds onto a bracket end)
       x = xn;
       break;
     }
@@ -455,7 +510,7 @@ M355_DEV double gammaincinv_p(double a, double p, double lga) {
     x = xn;
     // a small Newton / Halley step squares (or cubes) the error it leaves: converged.  Safeguard
     // (bisection-like) steps only converge linearly and run down to a few ulp.
-    if (dx <= (safeguarded ? 4.0 * kEps : (halley ? kRootStepHalley : kRootStep)) * x) break;
+    if (dx <= (safeguarded ? 4.0 * kEps : (halley ? halley_tol : newton_tol)) * x) break;
   }
   return x;
 }

@@ -69,6 +69,69 @@ def test_device_gammainc_vs_mpmath(gpu):
             assert abs(qi - mp.log(tq)) <= 1e-12 * max(1, abs(mp.log(tq))), (ai, xi)
 
 
+def test_device_gammainc_temme_region(gpu):
+    """a >= 25, |x - a| <= 0.3 a on the device (gammainc_temme; the host twin is test_host_gammainc_temme_region, whose
+    docstring says why SciPy stops being the reference at a > 1e5): gamma.logcdf / logsf with beta = 1 against SciPy
+    for a <= 1e5 and against the exact-coefficient 60-digit expansion for a up to 1e14, the quantile against SciPy
+    (a <= 1e5) and through the forward function (a <= 1e12); poisson.logcdf at mu up to 1e9 (poisson.py:71-75:
+    gammaincc(floor(x) + 1, mu)) against the same expansion."""
+    import os
+    import sys
+
+    import mpmath as mp
+
+    from distributions_amd import gamma, poisson
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tools"))
+    import gen_temme_coeffs as gen
+
+    def points(rng, n, lo, hi):
+        a = np.exp(rng.uniform(np.log(lo), np.log(hi), n))
+        sig = np.where(rng.uniform(size=n) < 0.5, rng.uniform(-0.3, 0.3, n), rng.normal(0, 2.0, n) / np.sqrt(a))
+        return a, a * (1 + np.clip(sig, -0.3, 0.3))
+
+    rng = np.random.default_rng(21)
+    a, x = points(rng, 40000, 25.0, 1e5)
+    with np.errstate(all="ignore"):
+        lo = x < a
+        for fn, f, side in (("logcdf", sp.gammainc, lo), ("logsf", sp.gammaincc, ~lo)):
+            got, direct = getattr(gamma, fn)(x, a, 1.0), f(a, x)
+            m = side & (direct > 1e-300)
+            assert m.sum() > 10000
+            ok = H.close(got[m], np.log(direct[m]), 1e-12)
+            assert np.all(ok), (fn, a[m][~ok][:4], x[m][~ok][:4], got[m][~ok][:4], np.log(direct[m][~ok][:4]))
+    a, x = points(rng, 1200, 1e5, 1e14)
+    lp, lq = gamma.logcdf(x, a, 1.0), gamma.logsf(x, a, 1.0)
+    mp.mp.dps = 60
+    _, exact = gen.coefficients()
+    checked = 0
+    for ai, xi, pi, qi in zip(a, x, lp, lq):
+        rp, rq = gen.temme_mp(exact, ai, xi)
+        ref, got = (rp, pi) if rp is not None else (rq, qi)
+        if ref > 1e-290:
+            lr = float(mp.log(ref))
+            assert abs(got - lr) <= 1e-12 * max(1.0, abs(lr)), (ai, xi, got, lr)
+            checked += 1
+    assert checked > 600
+    pr = rng.uniform(1e-6, 1 - 1e-6, 5000)
+    ai = np.exp(rng.uniform(np.log(25.0), np.log(1e5), 5000))
+    np.testing.assert_allclose(gamma.ppf(pr, ai, 1.0), sp.gammaincinv(ai, pr), rtol=1e-12)
+    ai = np.exp(rng.uniform(np.log(1e5), np.log(1e12), 5000))
+    root = gamma.ppf(pr, ai, 1.0)
+    back = gamma.cdf(root, ai, 1.0)
+    assert np.all(np.abs(back - pr) <= 1e-12 * pr + 2e-14 * np.sqrt(ai / (2 * np.pi)))
+    # poisson.logcdf(k, mu) = log Q(k + 1, mu)
+    mu = np.exp(rng.uniform(np.log(30.0), np.log(1e9), 400))
+    k = np.floor(mu + rng.normal(0, 2.0, mu.size) * np.sqrt(mu))
+    got = poisson.logcdf(k, mu)
+    for ki, mi, gi in zip(k, mu, got):
+        rp, rq = gen.temme_mp(exact, ki + 1.0, mi)
+        ref = rq if rq is not None else 1 - rp
+        if ref > 1e-290 and ref < 1 - 1e-9:
+            lr = float(mp.log(ref))
+            assert abs(gi - lr) <= 1e-12 * max(1.0, abs(lr)), (ki, mi, gi, lr)
+
+
 def test_device_gammaincinv_regimes(gpu):
     from distributions_amd import gamma
 

@@ -4,6 +4,7 @@ fractions and root finders against the oracle while no GPU is attached.  They ar
 tests: the hardware seeds and the device libm differ on the GPU; parity proper is `-m gpu`."""
 
 import ctypes
+import sys
 import os
 import subprocess
 import types
@@ -177,6 +178,64 @@ def test_host_gammainc(hostlib, arange):
         m = exp > 1e-300  # subnormal results carry fewer bits
         with np.errstate(all="ignore"):
             assert np.all(_close(np.log(got[m]), np.log(exp[m]), tol)), name
+
+
+def _temme_points(rng, n, lo, hi):
+    a = np.exp(rng.uniform(np.log(lo), np.log(hi), n))
+    sig = np.where(rng.uniform(size=n) < 0.5, rng.uniform(-0.3, 0.3, n), rng.normal(0, 2.0, n) / np.sqrt(a))
+    return a, a * (1 + np.clip(sig, -0.3, 0.3))
+
+
+def test_host_gammainc_temme_region(hostlib):
+    """a >= 25, |x - a| <= 0.3 a (Temme's uniform expansion, gammainc_temme), including |x - a| ~ sqrt(a), where P and Q
+    are both O(1) and the series / continued fraction would need ~sqrt(a) terms.  exp(-a phi) carries a phi ulps, hence
+    the comparison of logs at 1e-12 max(1, |log|).
+      a <= 1e5: against SciPy (igam / igamc take the same expansion there and hold 7e-16 in this measure);
+      a <= 1e14: against the expansion evaluated with exact rational coefficients in 60-digit arithmetic
+                 (tools/gen_temme_coeffs.py: agrees with mpmath's gammainc to 4e-25 for 200 <= a <= 1e4, and with direct
+                 quadrature of the density at a = 7.2e12, 2e9, 3.3e7).  SciPy is NOT the reference there: its tails
+                 drift from 5e-11 (a ~ 1e5) to tens of percent (a >= 1e8; e.g. gammainc(7207594366627.789,
+                 7207581856025.457) = 5.7e-9 against 1.58126e-6 by quadrature), so at such a the library follows the
+                 function, not the oracle's error -- DESIGN.md section 4."""
+    import mpmath as mp
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tools"))
+    import gen_temme_coeffs as gen
+
+    rng = np.random.default_rng(21)
+    a, x = _temme_points(rng, 40000, 25.0, 1e5)
+    a = np.concatenate([a, [25.0, 25.0, 25.0]])
+    x = np.concatenate([x, [25.0 * 0.7, 25.0, 25.0 * 1.3]])
+    for name, f in (("hm_gammainc", sp.gammainc), ("hm_gammaincc", sp.gammaincc)):
+        got, exp = vec(hostlib, name, a, x), f(a, x)
+        m = exp > 1e-300
+        with np.errstate(all="ignore"):
+            assert np.all(_close(np.log(got[m]), np.log(exp[m]), 1e-12)), name
+        assert np.all(got[~m] <= 1e-299)
+    a, x = _temme_points(rng, 1200, 1e5, 1e14)
+    a = np.concatenate([a, [1e300, 4e15]])
+    x = np.concatenate([x, [1e300, 4e15 + 1]])
+    p, q = vec(hostlib, "hm_gammainc", a, x), vec(hostlib, "hm_gammaincc", a, x)
+    assert np.max(np.abs(p + q - 1)) <= 4e-16
+    mp.mp.dps = 60
+    _, exact = gen.coefficients()
+    for ai, xi, pi, qi in zip(a[:-2], x[:-2], p, q):
+        rp, rq = gen.temme_mp(exact, ai, xi)
+        ref, got = (rp, pi) if rp is not None else (rq, qi)
+        if ref > 1e-290:
+            lr = float(mp.log(ref))
+            assert abs(np.log(got) - lr) <= 1e-12 * max(1.0, abs(lr)), (ai, xi, got, float(ref))
+    # a = 1e300: eta = 0, P = 1/2 - c_0(0)/sqrt(2 pi a)
+    assert abs(p[-2] - 0.5) <= 2.3e-16 and abs(q[-2] - 0.5) <= 2.3e-16
+    # the quantile through the same region: against SciPy where it is accurate, by the forward function beyond
+    pr = rng.uniform(1e-6, 1 - 1e-6, 5000)
+    ai = np.exp(rng.uniform(np.log(25.0), np.log(1e5), 5000))
+    assert_allclose(vec(hostlib, "hm_gammaincinv", ai, pr), sp.gammaincinv(ai, pr), rtol=1e-12)
+    ai = np.exp(rng.uniform(np.log(1e5), np.log(1e12), 5000))
+    root = vec(hostlib, "hm_gammaincinv", ai, pr)
+    back = vec(hostlib, "hm_gammainc", ai, root)
+    # dP/dx <= 1/sqrt(2 pi a): a relative error r of the root moves P by r a / sqrt(2 pi a); r <= 2e-14 (bar: 1e-12)
+    assert np.all(np.abs(back - pr) <= 1e-12 * pr + 2e-14 * np.sqrt(ai / (2 * np.pi)))
 
 
 def test_host_gammainc_betainc_vs_mpmath(hostlib):
