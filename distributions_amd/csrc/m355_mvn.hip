@@ -326,6 +326,123 @@ __global__ __launch_bounds__(64) void k_mvn_batched(const double* __restrict__ c
   cholesky_body<64, true>(cov, d, nullptr, nullptr, fa);
 }
 
+// One observation with its own covariance, d <= 64 (SURVEY 8(d) config 4 variant B), one wavefront per pair, everything
+// in registers: the lower triangle is held as 16x16 tiles in the A-operand layout of v_mfma_f64_16x16x4 (lane l, element
+// kk: T[l & 15][(l >> 4) + 4 kk]).  A tile in that layout serves as the A operand (= T) and as the B operand (= T^T),
+// and the D layout of X Y^T is the A layout of Y X^T, so a right-looking blocked Cholesky never leaves the registers:
+//   diagonal tile J:  through 2 KiB of LDS into row layout (lane = row), factored with v_readlane broadcasts exactly
+//                     like phase B of k_cholesky; W = inv(L_JJ) one column per lane, back through LDS into the A layout;
+//   column J below:   L_IJ = U_IJ W^T        as D = W U_IJ^T        (4 MFMAs per tile, operands straight from registers)
+//   trailing tiles:   T_IK -= L_IJ L_KJ^T    as D = (-L_KJ) L_IJ^T + T_IK
+// The observation rides along as one more block row (row 0 of tile (NB, J) = (x - mu)[16J ..]): the factor of the
+// bordered matrix has y = L^-1 (x - mu) in that row, so the forward substitution costs no code of its own and
+// quad = sum y^2 (mvnormal.py:30-32).  LDS per wavefront 4.3 KiB (k_mvn_batched of round 2 kept the matrix in LDS: 33 KiB,
+// four wavefronts per CU, 52 us per matrix in a chain of LDS round trips).
+template <int NB>
+__global__ __launch_bounds__(64, 2) void k_mvn_tiles(const double* __restrict__ cov, int d, const FusedArgs fa) {
+  __shared__ double stage[2][16 * 17];
+  const int lane = threadIdx.x, r16 = lane & 15, g = lane >> 4;
+  const long long b = blockIdx.x;
+  const double* src = cov + (size_t)b * d * d;
+  d4_t T[NB + 1][NB];
+#pragma unroll
+  for (int I = 0; I < NB; ++I) {
+#pragma unroll
+    for (int J = 0; J <= I; ++J) {
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        const int row = 16 * I + r16, col = 16 * J + g + 4 * kk;
+        T[I][J][kk] = (row < d && col < d) ? src[(size_t)row * d + col] : (row == col ? 1.0 : 0.0);
+      }
+    }
+  }
+  {
+    const double* xb = fa.x + b * d;
+    const double* mb = fa.mu + (fa.mu_stride ? b * fa.mu_stride : 0);
+#pragma unroll
+    for (int J = 0; J < NB; ++J) {
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        const int col = 16 * J + g + 4 * kk;
+        T[NB][J][kk] = (r16 == 0 && col < d) ? xb[col] - mb[col] : 0.0;
+      }
+    }
+  }
+  double mydiag = 1.0;  // product-free: lane r16 of group 0 collects log L_cc of its rows
+  double lg = 0.0, quad = 0.0;
+#pragma unroll
+  for (int J = 0; J < NB; ++J) {
+    // diagonal tile: A layout -> row layout
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) stage[0][r16 * 17 + g + 4 * kk] = T[J][J][kk];
+    __syncthreads();
+    double u[16], acc[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+      u[c] = stage[0][r16 * 17 + c];
+      acc[c] = 0.0;
+    }
+    // Column c of L_JJ and row c of W = inv(L_JJ) in the same sweep (lane = row r16 for L, = column r16 for W; the four
+    // lane groups carry copies): the multipliers L[c2][c] broadcast by v_readlane feed the right-looking Cholesky update
+    // u[c2] -= L[r16][c] L[c2][c] and the inverse's running sums acc[c2] = sum_{k<c2} L[c2][k] W[k][r16] alike.
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+      double piv, rinv;
+      sqrt_rsqrt(readlane_d(u[c], c), piv, rinv);
+      const double lc = (r16 == c) ? piv : (r16 > c ? u[c] * rinv : 0.0);
+      if (r16 == c) mydiag = piv;
+      const double xc = (c == r16) ? rinv : (c > r16 ? -acc[c] * rinv : 0.0);  // W[c][r16]
+      if (g == 0) stage[1][c * 17 + r16] = xc;
+#pragma unroll
+      for (int c2 = c + 1; c2 < 16; ++c2) {
+        const double m = readlane_d(lc, c2);  // L[c2][c]
+        u[c2] = __builtin_fma(-lc, m, u[c2]);
+        acc[c2] = __builtin_fma(m, xc, acc[c2]);
+      }
+    }
+    lg += flog(mydiag);  // log of a NaN pivot -> NaN
+    __syncthreads();
+    d4_t W;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) W[kk] = stage[1][r16 * 17 + g + 4 * kk];
+    // column J: L_IJ = U_IJ W^T for the rows below (and the observation row)
+#pragma unroll
+    for (int I = J + 1; I <= NB; ++I) {
+      d4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(W[kk], T[I][J][kk], acc, 0, 0, 0);
+      T[I][J] = acc;
+    }
+    // y_J = row 0 of the observation tile
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) quad = __builtin_fma(T[NB][J][kk], T[NB][J][kk], quad);
+    // trailing update
+#pragma unroll
+    for (int K = J + 1; K < NB; ++K) {
+#pragma unroll
+      for (int I = K; I <= NB; ++I) {
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+          T[I][K] = __builtin_amdgcn_mfma_f64_16x16x4f64(-T[K][J][kk], T[I][J][kk], T[I][K], 0, 0, 0);
+      }
+    }
+  }
+  // rows other than 0 of the observation tiles are zero, so quad needs the lanes r16 == 0 only; log diag: group 0
+  quad = (r16 == 0) ? quad : 0.0;
+  lg = (g == 0) ? lg : 0.0;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    quad += __shfl_xor(quad, o, 64);
+    lg += __shfl_xor(lg, o, 64);
+  }
+  if (lane == 0) {
+    const double logdet = 2.0 * lg;
+    double v = -0.5 * (fa.c0 + logdet + quad);  // mvnormal.py:82-83
+    if (fa.mode == 2) v = fa.c0 - 0.5 * (fa.nu + (double)d) * flog1p(quad / fa.nu) - 0.5 * logdet;  // mvstudentt.py:62-64
+    fa.out[b] = v;
+  }
+}
+
 struct SolveArgs {
   const double* x;       // observation r, component i: x[(r / inner) * s1 + (r % inner) * s2 + i * cs]
   const double* mu;      // same with mu_s1 (0 when mu is shared over the batch)
@@ -625,9 +742,12 @@ int run_cholesky(const double* cov, long long ncov, int d, double* ws, double* f
   return launched();
 }
 int run_batched(const double* cov, long long n, int d, const m355::FusedArgs& fa, hipStream_t s) {
-  const int dp = 16 * m355::nblk16(d);
-  const size_t lds = ((size_t)dp * (dp + 1) + 272 + dp) * sizeof(double);
-  hipLaunchKernelGGL(m355::k_mvn_batched, dim3((unsigned)n), dim3(64), lds, s, cov, d, fa);
+  switch (m355::nblk16(d)) {
+    case 1: hipLaunchKernelGGL(m355::k_mvn_tiles<1>, dim3((unsigned)n), dim3(64), 0, s, cov, d, fa); break;
+    case 2: hipLaunchKernelGGL(m355::k_mvn_tiles<2>, dim3((unsigned)n), dim3(64), 0, s, cov, d, fa); break;
+    case 3: hipLaunchKernelGGL(m355::k_mvn_tiles<3>, dim3((unsigned)n), dim3(64), 0, s, cov, d, fa); break;
+    default: hipLaunchKernelGGL(m355::k_mvn_tiles<4>, dim3((unsigned)n), dim3(64), 0, s, cov, d, fa); break;
+  }
   return launched();
 }
 template <int NB, bool MU_ROWS> int launch_mfma(const m355::MfmaArgs& a, hipStream_t s) {
