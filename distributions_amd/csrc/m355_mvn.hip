@@ -65,7 +65,10 @@ M355_DEV double readlane_d(double v, int lane) {  // `lane` must be wave-uniform
 
 // sqrt(a) and 1/sqrt(a) from the hardware rsq seed (coupled Newton steps, ~1 ulp each); a <= 0 or
 // NaN gives NaN for both (a non-positive pivot poisons the factor, as the reference's does).
-M355_DEV void sqrt_rsqrt(double a, double& root, double& inv_root) {
+// (CHECKED = false leaves out the final selects: a < 0 and NaN give NaN through v_rsq_f64 itself, a = 0 and a = inf
+// through 0 * inf in the first product -- only -0.0, whose rsq is -inf and whose root comes out as NaN as well, would
+// differ in no way either.  The selects are 6 of the ~18 operations.)
+template <bool CHECKED = true> M355_DEV void sqrt_rsqrt(double a, double& root, double& inv_root) {
   const double y = __builtin_amdgcn_rsq(a);
   double g = a * y, h = 0.5 * y;
   double r = __builtin_fma(-h, g, 0.5);
@@ -74,9 +77,14 @@ M355_DEV void sqrt_rsqrt(double a, double& root, double& inv_root) {
   g = __builtin_fma(__builtin_fma(-g, g, a), h, g);
   r = __builtin_fma(-h, g, 0.5);
   h = __builtin_fma(h, r, h);
-  const bool ok = a > 0.0;
-  root = ok ? g : kNaN;
-  inv_root = ok ? 2.0 * h : kNaN;
+  if constexpr (CHECKED) {
+    const bool ok = a > 0.0;
+    root = ok ? g : kNaN;
+    inv_root = ok ? 2.0 * h : kNaN;
+  } else {
+    root = g;
+    inv_root = 2.0 * h;
+  }
 }
 
 // Fragment of block (I, J), J <= I, k-step kk, lane l: element [row 16I + (l&15)][col 16J + (l>>4) + 4kk]
@@ -336,15 +344,17 @@ __global__ __launch_bounds__(64) void k_mvn_batched(const double* __restrict__ c
 //   trailing tiles:   T_IK -= L_IJ L_KJ^T    as D = (-L_KJ) L_IJ^T + T_IK
 // The observation rides along as one more block row (row 0 of tile (NB, J) = (x - mu)[16J ..]): the factor of the
 // bordered matrix has y = L^-1 (x - mu) in that row, so the forward substitution costs no code of its own and
-// quad = sum y^2 (mvnormal.py:30-32).  LDS per wavefront 4.3 KiB (k_mvn_batched of round 2 kept the matrix in LDS: 33 KiB,
+// quad = sum y^2 (mvnormal.py:30-32).  LDS per wavefront 10.6 KiB (k_mvn_batched of round 2 kept the matrix in LDS: 33 KiB,
 // four wavefronts per CU, 52 us per matrix in a chain of LDS round trips).
 template <int NB>
 __global__ __launch_bounds__(64, 2) void k_mvn_tiles(const double* __restrict__ cov, int d, const FusedArgs fa) {
-  __shared__ double stage[2][16 * 17];
+  __shared__ double stage[5][16 * 17];  // [0]: A layout -> row layout; [1 + g]: W of lane group g, column -> A layout
   const int lane = threadIdx.x, r16 = lane & 15, g = lane >> 4;
   const long long b = blockIdx.x;
   const double* src = cov + (size_t)b * d * d;
   d4_t T[NB + 1][NB];
+  // every load is issued unconditionally at a clamped address (no exec-mask branches around 56 loads); entries outside
+  // the d x d matrix are then replaced by the identity
 #pragma unroll
   for (int I = 0; I < NB; ++I) {
 #pragma unroll
@@ -352,7 +362,8 @@ __global__ __launch_bounds__(64, 2) void k_mvn_tiles(const double* __restrict__ 
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {
         const int row = 16 * I + r16, col = 16 * J + g + 4 * kk;
-        T[I][J][kk] = (row < d && col < d) ? src[(size_t)row * d + col] : (row == col ? 1.0 : 0.0);
+        const double v = src[(size_t)(row < d ? row : d - 1) * d + (col < d ? col : d - 1)];
+        T[I][J][kk] = (row < d && col < d) ? v : (row == col ? 1.0 : 0.0);
       }
     }
   }
@@ -363,8 +374,9 @@ __global__ __launch_bounds__(64, 2) void k_mvn_tiles(const double* __restrict__ 
     for (int J = 0; J < NB; ++J) {
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {
-        const int col = 16 * J + g + 4 * kk;
-        T[NB][J][kk] = (r16 == 0 && col < d) ? xb[col] - mb[col] : 0.0;
+        const int col = 16 * J + g + 4 * kk, cc = col < d ? col : d - 1;
+        const double v = xb[cc] - mb[cc];
+        T[NB][J][kk] = (r16 == 0 && col < d) ? v : 0.0;
       }
     }
   }
@@ -380,19 +392,22 @@ __global__ __launch_bounds__(64, 2) void k_mvn_tiles(const double* __restrict__ 
 #pragma unroll
     for (int c = 0; c < 16; ++c) {
       u[c] = stage[0][r16 * 17 + c];
-      acc[c] = 0.0;
+      acc[c] = (c == r16) ? -1.0 : 0.0;
     }
     // Column c of L_JJ and row c of W = inv(L_JJ) in the same sweep (lane = row r16 for L, = column r16 for W; the four
     // lane groups carry copies): the multipliers L[c2][c] broadcast by v_readlane feed the right-looking Cholesky update
     // u[c2] -= L[r16][c] L[c2][c] and the inverse's running sums acc[c2] = sum_{k<c2} L[c2][k] W[k][r16] alike.
+    // No selects: lanes r16 <= c hold finished rows, whatever lc is there only reaches their unused upper-triangle
+    // entries; W[c][r16] = -acc[c] / L_cc with acc[r16] started at -1 gives the diagonal, and the sums of the rows
+    // c < r16 are still 0 (W is lower triangular).
 #pragma unroll
     for (int c = 0; c < 16; ++c) {
       double piv, rinv;
-      sqrt_rsqrt(readlane_d(u[c], c), piv, rinv);
-      const double lc = (r16 == c) ? piv : (r16 > c ? u[c] * rinv : 0.0);
+      sqrt_rsqrt<false>(readlane_d(u[c], c), piv, rinv);
+      const double lc = u[c] * rinv;
       if (r16 == c) mydiag = piv;
-      const double xc = (c == r16) ? rinv : (c > r16 ? -acc[c] * rinv : 0.0);  // W[c][r16]
-      if (g == 0) stage[1][c * 17 + r16] = xc;
+      const double xc = -acc[c] * rinv;  // W[c][r16]
+      stage[1 + g][c * 17 + r16] = xc;
 #pragma unroll
       for (int c2 = c + 1; c2 < 16; ++c2) {
         const double m = readlane_d(lc, c2);  // L[c2][c]
@@ -404,7 +419,7 @@ __global__ __launch_bounds__(64, 2) void k_mvn_tiles(const double* __restrict__ 
     __syncthreads();
     d4_t W;
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) W[kk] = stage[1][r16 * 17 + g + 4 * kk];
+    for (int kk = 0; kk < 4; ++kk) W[kk] = stage[1 + g][r16 * 17 + g + 4 * kk];
     // column J: L_IJ = U_IJ W^T for the rows below (and the observation row)
 #pragma unroll
     for (int I = J + 1; I <= NB; ++I) {
