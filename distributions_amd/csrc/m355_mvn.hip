@@ -109,9 +109,8 @@ constexpr int kCholThreads = 256;
 // below 1e-12 (measured to cond(cov) = 1e10 against a long-double solve).  Larger d keeps substitution.
 constexpr int kFullInverseMaxNB = 4;
 
-// One observation with its own covariance (FUSED, one wavefront per matrix, d <= 64): after the factorisation the
-// forward substitution, the sum of squares and the epilogue run in the same workgroup from the factor in LDS, so a
-// matrix is read from HBM once and nothing but the result is written.
+// Arguments of k_mvn_tiles (one observation with its own covariance, d <= 64: factorisation, forward substitution, sum
+// of squares and epilogue in one wavefront -- a matrix is read from HBM once and nothing but the result is written).
 struct FusedArgs {
   const double* x;   // n x d
   const double* mu;  // d (mu_stride 0) or n x d
@@ -119,36 +118,28 @@ struct FusedArgs {
   double* out;
   int mode;          // 1: mvnormal logpdf, 2: mvstudentt logpdf
   double nu, c0;
+  long long n;       // number of (covariance, observation) pairs
 };
 
-template <int THREADS, bool FUSED>
-__device__ __forceinline__ void cholesky_body(const double* __restrict__ cov, int d, double* __restrict__ ws,
-                                              double* __restrict__ frags, const FusedArgs& fa) {
-  constexpr int kCholThreads = THREADS;
+__global__ __launch_bounds__(kCholThreads) void k_cholesky(const double* __restrict__ cov, int d,
+                                                            double* __restrict__ ws, double* __restrict__ frags) {
   extern __shared__ double a[];  // dp x S (S odd) | 16x16 diagonal block + 16 reciprocals | NB x 16 x 16 inverses | dp reciprocals
   const int NB = nblk16(d);
   const int dp = 16 * NB, S = dp + 1;
   double* diag = a + (size_t)dp * S;
   double* inv = diag + 272;
-  double* rdiag = inv + (FUSED ? 0 : (NB <= kFullInverseMaxNB ? NB * (NB + 1) / 2 : NB) * 256);
+  double* rdiag = inv + (NB <= kFullInverseMaxNB ? NB * (NB + 1) / 2 : NB) * 256;
   const double* src = cov + (size_t)blockIdx.x * d * d;
-  double* dst = FUSED ? nullptr : ws + (size_t)blockIdx.x * chol_stride(d);
+  double* dst = ws + (size_t)blockIdx.x * chol_stride(d);
   const int t = threadIdx.x, wave = t >> 6;
   // 2-D thread layout for the global <-> LDS copies: CW columns x (256 / CW) rows per step
   const int cshift = dp <= 16 ? 4 : (dp <= 32 ? 5 : (dp <= 64 ? 6 : 7));
   const int ccol = t & ((1 << cshift) - 1), crow0 = t >> cshift, crstep = kCholThreads >> cshift;
   M355_TICK(0);
   if (ccol < dp) {
-    if constexpr (FUSED) {
-      // one wavefront, four of them per CU (LDS): the matrix load is pure HBM latency, so keep 32 row loads in flight
-#pragma unroll 32
-      for (int r = crow0; r < dp; r += crstep)
-        a[r * S + ccol] = (r < d && ccol < d) ? __builtin_nontemporal_load(src + r * d + ccol) : (r == ccol ? 1.0 : 0.0);
-    } else {
 #pragma unroll 8
-      for (int r = crow0; r < dp; r += crstep)
-        a[r * S + ccol] = (r < d && ccol < d) ? src[r * d + ccol] : (r == ccol ? 1.0 : 0.0);
-    }
+    for (int r = crow0; r < dp; r += crstep)
+      a[r * S + ccol] = (r < d && ccol < d) ? src[r * d + ccol] : (r == ccol ? 1.0 : 0.0);
   }
   __syncthreads();
   M355_TICK(1);
@@ -226,28 +217,6 @@ __device__ __forceinline__ void cholesky_body(const double* __restrict__ cov, in
     M355_TICK(5 + 4 * J);
   }
   M355_TICK(40);
-  if constexpr (FUSED) {
-    // (one wavefront: lane = row)  logdet = 2 sum log diag; forward substitution by columns: y_k = acc_k / L_kk is
-    // broadcast from lane k, every later row takes acc_i -= y_k L_ik (one conflict-free LDS read per lane: odd stride)
-    double lg = (i < d) ? flog(ai[i]) : 0.0;  // log of a NaN diag -> NaN
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) lg += __shfl_xor(lg, o, 64);
-    const double logdet = 2.0 * lg;
-    const long long b = blockIdx.x;
-    double acc = (i < d) ? fa.x[b * d + i] - fa.mu[(fa.mu_stride ? b * fa.mu_stride : 0) + i] : 0.0;
-    double quad = 0.0;
-    for (int k = 0; k < d; ++k) {
-      const double yk = readlane_d(acc, k) * rdiag[k];
-      quad = __builtin_fma(yk, yk, quad);
-      acc = __builtin_fma(-yk, ai[k], acc);  // rows i <= k are finished: what happens to their acc is irrelevant
-    }
-    if (t == 0) {
-      double v = -0.5 * (fa.c0 + logdet + quad);  // mvnormal.py:82-83
-      if (fa.mode == 2) v = fa.c0 - 0.5 * (fa.nu + (double)d) * flog1p(quad / fa.nu) - 0.5 * logdet;  // mvstudentt.py:62-64
-      fa.out[b] = v;
-    }
-    return;
-  }
   if (ccol < d) {
 #pragma unroll 8
     for (int r = crow0; r < d; r += crstep) dst[r * d + ccol] = (ccol <= r) ? a[r * S + ccol] : 0.0;
@@ -260,7 +229,7 @@ __device__ __forceinline__ void cholesky_body(const double* __restrict__ cov, in
     for (int o = 32; o > 0; o >>= 1) lg += __shfl_down(lg, o, 64);
     if ((t & 63) == 0) diag[wave] = lg;
     __syncthreads();
-    if (t == 0) dst[(size_t)d * d + d] = 2.0 * (diag[0] + (THREADS > 64 ? diag[1] : 0.0));  // rows live in wavefronts 0 and 1 only
+    if (t == 0) dst[(size_t)d * d + d] = 2.0 * (diag[0] + diag[1]);  // rows live in wavefronts 0 and 1 only
   }
   M355_TICK(41);
   if (frags == nullptr) return;
@@ -325,131 +294,129 @@ __device__ __forceinline__ void cholesky_body(const double* __restrict__ cov, in
   M355_TICK(43);
 }
 
-__global__ __launch_bounds__(kCholThreads) void k_cholesky(const double* __restrict__ cov, int d,
-                                                            double* __restrict__ ws, double* __restrict__ frags) {
-  cholesky_body<kCholThreads, false>(cov, d, ws, frags, FusedArgs{});
-}
-// One wavefront per (covariance, observation) pair, d <= 64: factorisation, solve and epilogue fused.
-__global__ __launch_bounds__(64) void k_mvn_batched(const double* __restrict__ cov, int d, const FusedArgs fa) {
-  cholesky_body<64, true>(cov, d, nullptr, nullptr, fa);
-}
-
-// One observation with its own covariance, d <= 64 (SURVEY 8(d) config 4 variant B), one wavefront per pair, everything
-// in registers: the lower triangle is held as 16x16 tiles in the A-operand layout of v_mfma_f64_16x16x4 (lane l, element
-// kk: T[l & 15][(l >> 4) + 4 kk]).  A tile in that layout serves as the A operand (= T) and as the B operand (= T^T),
-// and the D layout of X Y^T is the A layout of Y X^T, so a right-looking blocked Cholesky never leaves the registers:
-//   diagonal tile J:  through 2 KiB of LDS into row layout (lane = row), factored with v_readlane broadcasts exactly
-//                     like phase B of k_cholesky; W = inv(L_JJ) one column per lane, back through LDS into the A layout;
-//   column J below:   L_IJ = U_IJ W^T        as D = W U_IJ^T        (4 MFMAs per tile, operands straight from registers)
-//   trailing tiles:   T_IK -= L_IJ L_KJ^T    as D = (-L_KJ) L_IJ^T + T_IK
-// The observation rides along as one more block row (row 0 of tile (NB, J) = (x - mu)[16J ..]): the factor of the
-// bordered matrix has y = L^-1 (x - mu) in that row, so the forward substitution costs no code of its own and
-// quad = sum y^2 (mvnormal.py:30-32).  LDS per wavefront 10.6 KiB (k_mvn_batched of round 2 kept the matrix in LDS: 33 KiB,
-// four wavefronts per CU, 52 us per matrix in a chain of LDS round trips).
+// One observation with its own covariance, d <= 64 (SURVEY 8(d) config 4 variant B): one wavefront per pair, the matrix
+// in registers.  The lower triangle is held as 16x16 tiles in the A-operand layout of v_mfma_f64_16x16x4 (lane l,
+// element kk: T[l & 15][(l >> 4) + 4 kk]).  A tile in that layout serves as the A operand (= T) and as the B operand
+// (= T^T), and the D layout of X Y^T is the A layout of Y X^T, so the trailing updates of a right-looking blocked
+// Cholesky,  T_IK -= L_IJ L_KJ^T  as  D = (-L_KJ) L_IJ^T + T_IK,  take every operand straight from registers.
+// Panel J (16 columns) is factored in row layout, lane i = matrix row i, reached through a 64 x 17 LDS buffer: column c
+// takes its pivot from lane 16J + c and its multipliers L[c2][c] from the lanes below by v_readlane, and since
+// l_c = u_c / L_cc is formed in every lane the same sweep is the triangular solve of all the tiles under the diagonal one
+// (no block inverse, no MFMA for it).  The observation rides along as one value per lane, b_i: y_c = b_{16J+c} / L_cc
+// (a broadcast), b_i -= y_c L_ic for every row below, quad += y_c^2 (mvnormal.py:30-32) -- the forward substitution
+// costs five operations per column.  Finished rows (lanes < 16J + c) keep computing on values nobody reads: no selects.
+// LDS 8.7 KiB per wavefront (k_mvn_batched of round 2 kept the matrix in LDS: 33 KiB, four wavefronts per CU, 52 us per
+// matrix in a chain of LDS round trips).
 template <int NB>
-__global__ __launch_bounds__(64, 2) void k_mvn_tiles(const double* __restrict__ cov, int d, const FusedArgs fa) {
-  __shared__ double stage[5][16 * 17];  // [0]: A layout -> row layout; [1 + g]: W of lane group g, column -> A layout
+__global__ __launch_bounds__(64, 3) void k_mvn_tiles(const double* __restrict__ cov, int d, const FusedArgs fa) {
+  __shared__ double P[64 * 17];
   const int lane = threadIdx.x, r16 = lane & 15, g = lane >> 4;
+  const int prow = lane < 16 * NB ? lane : 16 * NB - 1;  // (NB < 4: the lanes past the matrix shadow its last row)
+  // (one workgroup per pair: a wavefront that walks several pairs needs the tile registers across the loop's back edge
+  // and spills -- 284 bytes of scratch per lane, 1.45 ms instead of 1.04)
   const long long b = blockIdx.x;
   const double* src = cov + (size_t)b * d * d;
-  d4_t T[NB + 1][NB];
-  // every load is issued unconditionally at a clamped address (no exec-mask branches around 56 loads); entries outside
-  // the d x d matrix are then replaced by the identity
-#pragma unroll
-  for (int I = 0; I < NB; ++I) {
-#pragma unroll
-    for (int J = 0; J <= I; ++J) {
-#pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
-        const int row = 16 * I + r16, col = 16 * J + g + 4 * kk;
-        const double v = src[(size_t)(row < d ? row : d - 1) * d + (col < d ? col : d - 1)];
-        T[I][J][kk] = (row < d && col < d) ? v : (row == col ? 1.0 : 0.0);
-      }
-    }
-  }
-  {
-    const double* xb = fa.x + b * d;
-    const double* mb = fa.mu + (fa.mu_stride ? b * fa.mu_stride : 0);
+  d4_t T[NB][NB];
+  if (d == 16 * NB) {
+    // full tiles: one 32-bit lane offset, block-row bases in scalar registers, the rest immediate offsets
+    const int loff = r16 * d + g;
 #pragma unroll
     for (int J = 0; J < NB; ++J) {
 #pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
-        const int col = 16 * J + g + 4 * kk, cc = col < d ? col : d - 1;
-        const double v = xb[cc] - mb[cc];
-        T[NB][J][kk] = (r16 == 0 && col < d) ? v : 0.0;
+      for (int I = J; I < NB; ++I) {
+        const double* base = src + (size_t)(16 * I) * d + 16 * J;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) T[I][J][kk] = base[loff + 4 * kk];
+      }
+    }
+  } else {
+    // every load is issued unconditionally at a clamped address (no exec-mask branches around the loads); entries
+    // outside the d x d matrix are then replaced by the identity
+#pragma unroll
+    for (int J = 0; J < NB; ++J) {
+#pragma unroll
+      for (int I = J; I < NB; ++I) {
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+          const int row = 16 * I + r16, col = 16 * J + g + 4 * kk;
+          const double v = src[(size_t)(row < d ? row : d - 1) * d + (col < d ? col : d - 1)];
+          T[I][J][kk] = (row < d && col < d) ? v : (row == col ? 1.0 : 0.0);
+        }
       }
     }
   }
-  double mydiag = 1.0;  // product-free: lane r16 of group 0 collects log L_cc of its rows
-  double lg = 0.0, quad = 0.0;
+  double bcur;  // (x - mu)[lane], then the running right-hand side of the forward substitution
+  {
+    const int cc = lane < d ? lane : d - 1;
+    const double v = fa.x[b * d + cc] - fa.mu[(fa.mu_stride ? b * fa.mu_stride : 0) + cc];
+    bcur = lane < d ? v : 0.0;
+  }
+  double mydiag = 1.0, quad = 0.0;
 #pragma unroll
   for (int J = 0; J < NB; ++J) {
-    // diagonal tile: A layout -> row layout
+    // column J of tiles: A layout -> row layout
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) stage[0][r16 * 17 + g + 4 * kk] = T[J][J][kk];
-    __syncthreads();
-    double u[16], acc[16];
+    for (int I = J; I < NB; ++I) {
 #pragma unroll
-    for (int c = 0; c < 16; ++c) {
-      u[c] = stage[0][r16 * 17 + c];
-      acc[c] = (c == r16) ? -1.0 : 0.0;
+      for (int kk = 0; kk < 4; ++kk) P[(16 * I + r16) * 17 + g + 4 * kk] = T[I][J][kk];
     }
-    // Column c of L_JJ and row c of W = inv(L_JJ) in the same sweep (lane = row r16 for L, = column r16 for W; the four
-    // lane groups carry copies): the multipliers L[c2][c] broadcast by v_readlane feed the right-looking Cholesky update
-    // u[c2] -= L[r16][c] L[c2][c] and the inverse's running sums acc[c2] = sum_{k<c2} L[c2][k] W[k][r16] alike.
-    // No selects: lanes r16 <= c hold finished rows, whatever lc is there only reaches their unused upper-triangle
-    // entries; W[c][r16] = -acc[c] / L_cc with acc[r16] started at -1 gives the diagonal, and the sums of the rows
-    // c < r16 are still 0 (W is lower triangular).
+    __syncthreads();
+    double u[16], l[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) u[c] = P[prow * 17 + c];
 #pragma unroll
     for (int c = 0; c < 16; ++c) {
       double piv, rinv;
-      sqrt_rsqrt<false>(readlane_d(u[c], c), piv, rinv);
+      sqrt_rsqrt<false>(readlane_d(u[c], 16 * J + c), piv, rinv);
       const double lc = u[c] * rinv;
-      if (r16 == c) mydiag = piv;
-      const double xc = -acc[c] * rinv;  // W[c][r16]
-      stage[1 + g][c * 17 + r16] = xc;
+      l[c] = lc;
+      if (lane == 16 * J + c) mydiag = piv;
+      const double yc = readlane_d(bcur, 16 * J + c) * rinv;
+      quad = __builtin_fma(yc, yc, quad);
+      bcur = __builtin_fma(-yc, lc, bcur);
+      // multipliers four at a time: a v_readlane result needs two wait states before a VALU reads it, which the
+      // next broadcasts fill (one pair at a time the compiler reuses one SGPR pair and pads every FMA with s_nop)
 #pragma unroll
-      for (int c2 = c + 1; c2 < 16; ++c2) {
-        const double m = readlane_d(lc, c2);  // L[c2][c]
-        u[c2] = __builtin_fma(-lc, m, u[c2]);
-        acc[c2] = __builtin_fma(m, xc, acc[c2]);
+      for (int c0 = c + 1; c0 < 16; c0 += 4) {
+        double m[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) m[q] = (c0 + q < 16) ? readlane_d(lc, 16 * J + (c0 + q < 16 ? c0 + q : 15)) : 0.0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          if (c0 + q < 16) u[c0 + q] = __builtin_fma(-lc, m[q], u[c0 + q]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
-    lg += flog(mydiag);  // log of a NaN pivot -> NaN
-    __syncthreads();
-    d4_t W;
+    {
+      if (J + 1 < NB) {
+        // the tiles under the diagonal one go back to the A layout for the trailing updates
+        __syncthreads();
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) W[kk] = stage[1 + g][r16 * 17 + g + 4 * kk];
-    // column J: L_IJ = U_IJ W^T for the rows below (and the observation row)
+        for (int c = 0; c < 16; ++c) P[lane * 17 + c] = l[c];
+        __syncthreads();
+        d4_t L[NB];
 #pragma unroll
-    for (int I = J + 1; I <= NB; ++I) {
-      d4_t acc = {0.0, 0.0, 0.0, 0.0};
+        for (int I = J + 1; I < NB; ++I) {
 #pragma unroll
-      for (int kk = 0; kk < 4; ++kk) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(W[kk], T[I][J][kk], acc, 0, 0, 0);
-      T[I][J] = acc;
-    }
-    // y_J = row 0 of the observation tile
+          for (int kk = 0; kk < 4; ++kk) L[I][kk] = P[(16 * I + r16) * 17 + g + 4 * kk];
+        }
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) quad = __builtin_fma(T[NB][J][kk], T[NB][J][kk], quad);
-    // trailing update
+        for (int K = J + 1; K < NB; ++K) {
 #pragma unroll
-    for (int K = J + 1; K < NB; ++K) {
+          for (int I = K; I < NB; ++I) {
 #pragma unroll
-      for (int I = K; I <= NB; ++I) {
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk)
-          T[I][K] = __builtin_amdgcn_mfma_f64_16x16x4f64(-T[K][J][kk], T[I][J][kk], T[I][K], 0, 0, 0);
+            for (int kk = 0; kk < 4; ++kk) T[I][K] = __builtin_amdgcn_mfma_f64_16x16x4f64(-L[K][kk], L[I][kk], T[I][K], 0, 0, 0);
+          }
+        }
+        __syncthreads();
       }
     }
   }
-  // rows other than 0 of the observation tiles are zero, so quad needs the lanes r16 == 0 only; log diag: group 0
-  quad = (r16 == 0) ? quad : 0.0;
-  lg = (g == 0) ? lg : 0.0;
+  // quad is wave-uniform; log diag(L): lane i holds L_ii (identity padding: log 1 = 0; a NaN pivot -> NaN)
+  double lg = flog(mydiag);
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    quad += __shfl_xor(quad, o, 64);
-    lg += __shfl_xor(lg, o, 64);
-  }
+  for (int o = 32; o > 0; o >>= 1) lg += __shfl_xor(lg, o, 64);
   if (lane == 0) {
     const double logdet = 2.0 * lg;
     double v = -0.5 * (fa.c0 + logdet + quad);  // mvnormal.py:82-83
@@ -756,14 +723,17 @@ int run_cholesky(const double* cov, long long ncov, int d, double* ws, double* f
   hipLaunchKernelGGL(m355::k_cholesky, dim3((unsigned)ncov), dim3(threads), lds, s, cov, d, ws, frags);
   return launched();
 }
+template <int NB> int launch_tiles(const double* cov, long long n, int d, const m355::FusedArgs& fa, hipStream_t s) {
+  hipLaunchKernelGGL(m355::k_mvn_tiles<NB>, dim3((unsigned)n), dim3(64), 0, s, cov, d, fa);
+  return launched();
+}
 int run_batched(const double* cov, long long n, int d, const m355::FusedArgs& fa, hipStream_t s) {
   switch (m355::nblk16(d)) {
-    case 1: hipLaunchKernelGGL(m355::k_mvn_tiles<1>, dim3((unsigned)n), dim3(64), 0, s, cov, d, fa); break;
-    case 2: hipLaunchKernelGGL(m355::k_mvn_tiles<2>, dim3((unsigned)n), dim3(64), 0, s, cov, d, fa); break;
-    case 3: hipLaunchKernelGGL(m355::k_mvn_tiles<3>, dim3((unsigned)n), dim3(64), 0, s, cov, d, fa); break;
-    default: hipLaunchKernelGGL(m355::k_mvn_tiles<4>, dim3((unsigned)n), dim3(64), 0, s, cov, d, fa); break;
+    case 1: return launch_tiles<1>(cov, n, d, fa, s);
+    case 2: return launch_tiles<2>(cov, n, d, fa, s);
+    case 3: return launch_tiles<3>(cov, n, d, fa, s);
+    default: return launch_tiles<4>(cov, n, d, fa, s);
   }
-  return launched();
 }
 template <int NB, bool MU_ROWS> int launch_mfma(const m355::MfmaArgs& a, hipStream_t s) {
   constexpr bool REGF = NB <= m355::kFullInverseMaxNB;  // W = L^-1 blocks in registers (80 VGPRs at NB = 4)
@@ -841,7 +811,7 @@ extern "C" int m355_mvn_logpdf(int kind, int64_t n, int d, const double* x, cons
   if (d <= 64 && ncov == n && cov_div == 1 && cov_mod == n && n > 1 && n <= 0x7fffffffLL) {
     // one covariance per observation: fused factorisation + solve, one wavefront per pair, no factor written
     const double lt = kind == 1 ? lgamma((nu + d) / 2.0) - lgamma(nu / 2.0) - 0.5 * d * log(nu * 3.14159265358979323846) : 0.0;
-    FusedArgs fa{x, mu, (long long)mu_stride, out, kind == 0 ? 1 : 2, nu, kind == 0 ? lognorm_n0 : lt};
+    FusedArgs fa{x, mu, (long long)mu_stride, out, kind == 0 ? 1 : 2, nu, kind == 0 ? lognorm_n0 : lt, (long long)n};
     return run_batched(cov, n, d, fa, s);
   }
   int rc = run_cholesky(cov, ncov, d, ws, frags, s);
