@@ -154,11 +154,13 @@ def test_one_dim_value_against_batched_parameters(gpu):
     assert got.shape == (2, 3) and np.all(H.close(got, R.mvnormal_logpdf(x, mu[0], cov2)))
 
 
-@pytest.mark.parametrize("d", [64, 33, 7, 1])
+@pytest.mark.parametrize("d", [64, 63, 48, 33, 32, 17, 16, 7, 1])
 def test_one_covariance_per_observation_fused(gpu, d):
     """SURVEY.md 8(d) config 4, variant B: cov carries the batch axis (mvnormal.py:27) -- one wavefront factors each
-    matrix and solves its observation in the same workgroup (k_mvn_batched).  1e-12 against the restatement, shared
-    and per-row means, both kinds; a non-positive-definite matrix gives NaN for its row only (quirk Q5)."""
+    matrix in registers and solves its observation (k_mvn_tiles; d covers every tile count, the full-tile load path at
+    16 / 32 / 48 / 64 and the clamped one next to them).  1e-12 against the restatement, shared and per-row means, both
+    kinds; a non-positive-definite matrix gives NaN for its row only (quirk Q5); only the lower triangle of a
+    covariance is read (numpy.linalg.cholesky's contract, mvnormal.py:9-14)."""
     from distributions_amd import mvnormal, mvstudentt
 
     rng = np.random.default_rng(91 + d)
@@ -178,3 +180,10 @@ def test_one_covariance_per_observation_fused(gpu, d):
         bad[5] = -np.eye(d)
         got = mvnormal.logpdf(X, mu, bad)
         assert np.isnan(got[5]) and np.all(H.close(np.delete(got, 5), np.delete(R.mvnormal_logpdf(X, mu, cov), 5)))
+        semi = cov.copy()
+        semi[7, :, -1] = 0.0  # a zero last pivot: log(0) - and 0/0 in the solve
+        semi[7, -1, :] = 0.0
+        got = mvnormal.logpdf(X, mu, semi)
+        assert not np.isfinite(got[7]) and np.all(H.close(np.delete(got, 7), np.delete(R.mvnormal_logpdf(X, mu, cov), 7)))
+        junk = cov + np.triu(rng.normal(size=(n, d, d)) * 50.0, 1)  # strictly upper part overwritten
+        assert np.array_equal(mvnormal.logpdf(X, mu, junk), mvnormal.logpdf(X, mu, cov))
