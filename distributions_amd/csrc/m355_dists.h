@@ -459,18 +459,27 @@ template <> struct Dist<M355_BINOMIAL> {
     k.log1mp = flog1p(-p[1]);
     return k;
   }
-  static M355_DEV double logpdf(double x, const K& k) {  // binomial.py:66-75
+  static constexpr bool kLogTable = true;  // (top-level logpdf / pdf only: the pmf inside ppf runs where k_binned has no table)
+  template <bool TAB> static M355_DEV double logpdf_t(double x, const K& k) {  // binomial.py:66-75
     const double nmx = k.n - x;
-    double r = k.lgn1 - lgamma1p_obs(x) - lgamma1p_obs(nmx) + xlogy0_l(x, k.logp) + nmx * k.log1mp;
+    if constexpr (TAB) {
+      // counts and their complements both large (a wave-uniform fact for most data): the two log-factorials together
+      if (wave_all((x >= 128.0) & (nmx >= 128.0) & (k.n < 1e150))) {
+        const double r = (k.lgn1 - lgamma_obs_pair_big(x + 1.0, nmx + 1.0)) + __builtin_fma(x, k.logp, nmx * k.log1mp);
+        return r;  // (0 < x < n here)
+      }
+    }
+    double r = k.lgn1 - lgamma1p_obs<TAB>(x) - lgamma1p_obs<TAB>(nmx) + xlogy0_l(x, k.logp) + nmx * k.log1mp;
     return ((x < 0.0) | (x > k.n)) ? -kInf : r;
   }
+  static M355_DEV double logpdf(double x, const K& k) { return logpdf_t<false>(x, k); }
   static M355_DEV double cdf(double x, const K& k) {  // binomial.py:45-46
     const double a = k.n - x, b = x + 1.0;
     return cdf_bounds(betainc_(a, b, 1.0 - k.p, lbeta_(a, b)), x, 0.0, k.n);
   }
   template <int FN> static M355_DEV double eval(double x, const K& k) {
-    if constexpr (FN == M355_LOGPDF) return logpdf(x, k);
-    if constexpr (FN == M355_PDF) return exp_(logpdf(x, k));    // binomial.py:41-42
+    if constexpr (FN == M355_LOGPDF) return logpdf_t<true>(x, k);
+    if constexpr (FN == M355_PDF) return exp_(logpdf_t<true>(x, k));    // binomial.py:41-42
     if constexpr (FN == M355_CDF) return cdf(x, k);
     if constexpr (FN == M355_SF) return 1.0 - cdf(x, k);        // binomial.py:54-55
     if constexpr (FN == M355_LOGCDF) return flog(cdf(x, k));    // binomial.py:78-79

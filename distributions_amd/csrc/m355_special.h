@@ -62,25 +62,56 @@ M355_DEV double pow_l(double x, double lx, double y) { (void)lx; return std::pow
 // series (DLMF 5.11.1 through z^-11: |error| < 2e-18 at z = x + 1 >= 16) with one logarithm and one reciprocal above,
 // the device libm's lgamma for everything else (non-integers below 15, negative arguments and their poles, inf, NaN).
 // ~30 fp64-op equivalents instead of ~90: poisson.logpdf goes from lgamma-bound to the HBM stream.
-M355_DEV double lgamma_obs(double z) {  // log Gamma(z), z = a count + 1 (or a count + a parameter)
+// TAB: the logarithm comes from the LDS table (flog_tab, 14 operations instead of 25) -- for bodies whose kernel has
+// filled it (Dist<>::kLogTable; top-level logpdf / pdf only, see k_binned).  The reciprocal of the Stirling correction
+// takes one Newton step on the hardware seed (2^-48): the correction is below 1/(12 z) <= 5e-3 where the result is
+// above 28, so that is 2e-17 of absolute error.
+template <bool TAB = false> M355_DEV double lgamma_obs(double z) {  // log Gamma(z), z = a count + 1 (or a count + a parameter)
   constexpr double kLogFact[128] = {M355_LOGFACT128};
   if ((z >= 1.0) & (z < 129.0)) {
     const int i = (int)z;
     if ((double)i == z) return kLogFact[i - 1];
   }
   if ((z >= 16.0) & (z < 1e300)) {
-    const double w = rcp(z), w2 = w * w;
+    double w = hw_rcp(z);
+    w = __builtin_fma(__builtin_fma(-z, w, 1.0), w, w);
+    const double w2 = w * w;
     double p = -691.0 / 360360.0;
     p = __builtin_fma(p, w2, 1.0 / 1188.0);
     p = __builtin_fma(p, w2, -1.0 / 1680.0);
     p = __builtin_fma(p, w2, 1.0 / 1260.0);
     p = __builtin_fma(p, w2, -1.0 / 360.0);
     p = __builtin_fma(p, w2, 1.0 / 12.0);
-    return (((z - 0.5) * flog_pos(z) - z) + kLogSqrt2Pi) + p * w;
+    double lz;
+    if constexpr (TAB) lz = flog_tab(z);
+    else lz = flog_pos(z);
+    return (((z - 0.5) * lz - z) + kLogSqrt2Pi) + p * w;
   }
   return lgamma_(z);
 }
-M355_DEV double lgamma1p_obs(double x) { return lgamma_obs(x + 1.0); }
+template <bool TAB = false> M355_DEV double lgamma1p_obs(double x) { return lgamma_obs<TAB>(x + 1.0); }
+// log Gamma(z1) + log Gamma(z2) for 129 <= z1, z2 < 1e150 (every lane of the wavefront: the caller votes), table
+// logarithms: straight-line code, one reciprocal for both corrections (1/z1 = z2 / (z1 z2)), Stirling through z^-5
+// (the next term, 1/(1680 z^7), is below 1e-18 from z = 129).
+M355_DEV double lgamma_obs_pair_big(double z1, double z2) {
+  double r = hw_rcp(z1 * z2);
+  r = __builtin_fma(__builtin_fma(-(z1 * z2), r, 1.0), r, r);
+  const double w1 = z2 * r, w2 = z1 * r;
+  const double u1 = w1 * w1, u2 = w2 * w2;
+  const double c1 = __builtin_fma(__builtin_fma(1.0 / 1260.0, u1, -1.0 / 360.0), u1, 1.0 / 12.0) * w1;
+  const double c2 = __builtin_fma(__builtin_fma(1.0 / 1260.0, u2, -1.0 / 360.0), u2, 1.0 / 12.0) * w2;
+  const double a1 = __builtin_fma(z1 - 0.5, flog_tab(z1), -z1);
+  const double a2 = __builtin_fma(z2 - 0.5, flog_tab(z2), -z2);
+  return ((a1 + a2) + 2.0 * kLogSqrt2Pi) + (c1 + c2);
+}
+// true when every active lane satisfies `c` (host build: the single "lane")
+M355_DEV bool wave_all(bool c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __all(c) != 0;
+#else
+  return c;
+#endif
+}
 
 // pt.log1mexp: log(1 - exp(x)) for x <= 0.
 // ---- erfcx / erfinv, hand-written (tools/gen_erf_coeffs.py; the device libm's versions branch three ways and cost

@@ -361,6 +361,41 @@ def test_discrete_families_dense_parity(gpu, name, params, support):
         assert abs(tot - math.fsum(exp[fin])) <= 1e-12 * float(np.abs(exp[fin]).sum())
 
 
+@pytest.mark.parametrize("n, p", [(1000.0, 0.3), (300.0, 0.5), (1e5, 0.02), (1e7, 0.7), (1e12, 0.5)])
+def test_binomial_logpmf_large_counts(gpu, n, p):
+    """binomial.logpdf where every lane of a wavefront has x >= 128 and n - x >= 128 takes the paired log-factorial
+    (lgamma_obs_pair_big: table logarithms, one shared reciprocal, binomial.py:66-75), wavefronts with a small count, a
+    value outside the support or a non-integer among their lanes the general body; both against the oracle, whose own
+    three gammaln terms carry ~eps * gammaln(n + 1) of rounding -- hence the bar 1e-12 max(1, |b|) + 4 eps gammaln(n + 1)."""
+    from scipy.special import gammaln
+
+    from distributions_amd import binomial
+
+    rng = np.random.default_rng(int(n) % 1000 + 3)
+    x = rng.binomial(int(n), p, 300_000).astype(np.float64)
+    mixed = x.copy()
+    mixed[::37] = rng.integers(0, 130, mixed[::37].size)  # small counts: table branch in some wavefronts
+    mixed[5::53] = -1.0
+    mixed[7::59] = n + 1.0
+    mixed[11::61] += 0.5
+    for pts in (x, mixed, x.astype(np.int64)):
+        with np.errstate(all="ignore"):
+            exp = R.TABLE["binomial_logpdf"](np.asarray(pts, dtype=np.float64), n, p)
+        got = binomial.logpdf(pts, n, p)
+        assert np.array_equal(np.isneginf(got), np.isneginf(exp)) and np.array_equal(np.isnan(got), np.isnan(exp))
+        fin = np.isfinite(exp)
+        err = np.abs(got[fin] - exp[fin])
+        assert np.all(err <= 1e-12 * np.maximum(1.0, np.abs(exp[fin])) + 4 * 2.3e-16 * gammaln(n + 1.0)), (n, p, err.max())
+    if n <= 1e7:  # against exact integer arithmetic: log of the exact rational pmf
+        import mpmath as mp
+
+        mp.mp.dps = 40
+        for xi in x[:40]:
+            ref = mp.log(mp.binomial(int(n), int(xi))) + xi * mp.log(p) + (n - xi) * mp.log1p(-mp.mpf(p))
+            gi = binomial.logpdf(np.array([xi] * 64), n, p)[0]
+            assert abs(gi - ref) <= 1e-12 * max(1.0, abs(ref)) + 4 * 2.3e-16 * float(gammaln(n + 1.0)), (n, p, xi)
+
+
 @pytest.mark.parametrize("h, z", H.POLYAGAMMA_CASES)
 def test_polyagamma(gpu, h, z):
     """polyagamma: no SciPy counterpart -- every function against the oracle (series density,
