@@ -5,6 +5,7 @@
 // arm's NaNs never leak).  file:line citations refer to /root/reference/pytensor_distributions.
 #pragma once
 #include "m355_math.h"
+#include "m355_logphitab.h"
 #include "m355_special.h"
 #include "../../include/m355_dist.h"
 
@@ -56,8 +57,40 @@ M355_DEV double standardise(double d, double sigma, double inv_sigma) {
   return (q - q == 0.0) ? v : q;  // inf / NaN quotients pass through (the residual would be inf - inf)
 }
 
+// log Phi(z) from a piecewise polynomial (tools/gen_logphi_table.py -> m355_logphitab.h: 256 cells on [-10, 6), degree
+// 8, 2.2e-16 of max(1, |log Phi|)) held in LDS: ~8 operations for the cell and nine fused multiply-adds instead of an
+// erfcx, an exponential and a logarithm (~160).  For the kernels with scalar parameters (k_scalar fills the table);
+// z outside the table, NaN included, takes normal_logcdf_z.
+#if defined(__HIP_DEVICE_COMPILE__)
+static __device__ const double g_phi_table_rom[kPhiCells * kPhiStride] = {M355_LOGPHI_TABLE};
+static __shared__ double g_phi_table[kPhiCells * kPhiStride];
+M355_DEV void phi_table_init() {
+  for (int i = threadIdx.x; i < kPhiCells * kPhiStride; i += blockDim.x) g_phi_table[i] = g_phi_table_rom[i];
+  __syncthreads();
+}
+M355_DEV const double* phi_cell(int i) { return g_phi_table + i * kPhiStride; }
+#else
+static const double g_phi_table_rom[kPhiCells * kPhiStride] = {M355_LOGPHI_TABLE};
+M355_HD void phi_table_init() {}
+M355_HD const double* phi_cell(int i) { return g_phi_table_rom + i * kPhiStride; }
+#endif
+M355_DEV double normal_logcdf_z_tab(double z) {
+  const double s = __builtin_fma(z, kPhiCellsPerUnit, -kPhiLo * kPhiCellsPerUnit);  // cell number + position in it
+  if (!((s >= 0.0) & (s < (double)kPhiCells))) return normal_logcdf_z(z);
+  const double fi = __builtin_floor(s);
+  const double t = __builtin_fma(2.0, s - fi, -1.0);
+  const double* c = phi_cell((int)fi);
+  double p = c[kPhiDeg];
+#pragma unroll
+  for (int k = kPhiDeg - 1; k >= 0; --k) p = __builtin_fma(p, t, c[k]);
+  return p;
+}
+
 template <> struct Dist<M355_NORMAL> {
   static constexpr int NP = 2;
+  // k_scalar evaluates these through eval_tab after phi_table_init()
+  static constexpr bool tab_fn(int fn) { return fn == M355_LOGCDF || fn == M355_LOGSF || fn == M355_SF; }
+
   struct K {
     double mu, sigma, inv_sigma, c;
   };
@@ -90,6 +123,11 @@ template <> struct Dist<M355_NORMAL> {
       return ppf_bounds_cont(v, q, -kInf, kInf);
     }
     return kNaN;
+  }
+  template <int FN> static M355_DEV double eval_tab(double x, const K& k) {
+    if constexpr (FN == M355_LOGCDF) return normal_logcdf_z_tab(standardise(x - k.mu, k.sigma, k.inv_sigma));
+    else if constexpr (FN == M355_LOGSF) return normal_logcdf_z_tab(standardise(-x + k.mu, k.sigma, k.inv_sigma));
+    else return exp_(normal_logcdf_z_tab((-x + k.mu) / k.sigma));  // M355_SF
   }
 };
 

@@ -136,11 +136,25 @@ constexpr int kRenormEvery = 64;  // tiles (4 elements per thread each) between 
 template <class T, class = void> struct has_f32_body : std::false_type {};
 template <class T> struct has_f32_body<T, std::void_t<decltype(&T::logpdf_f32)>> : std::true_type {};
 
+// Dist<D>::tab_fn(fn) / eval_tab<FN>: a body for the scalar-parameter kernels that reads an LDS table which
+// phi_table_init() fills (normal.logcdf / logsf / sf, m355_dists.h).
+template <class T, class = void> struct has_tab_body : std::false_type {};
+template <class T> struct has_tab_body<T, std::void_t<decltype(&T::tab_fn)>> : std::true_type {};
+template <class DD, int FN> constexpr bool use_tab_body() {
+  if constexpr (has_tab_body<DD>::value) return DD::tab_fn(FN);
+  else return false;
+}
+template <class DD, int FN> M355_DEV double eval_scalar(double x, const typename DD::K& k) {
+  if constexpr (use_tab_body<DD, FN>()) return DD::template eval_tab<FN>(x, k);
+  else return DD::template eval<FN>(x, k);
+}
+
 template <int D, int FN, bool REDUCE, int IO>
 M355_DEV void scalar_body(const void* __restrict__ x, int xdt, void* __restrict__ out, int odt, long long n,
                           const typename Dist<D>::K& k, double* __restrict__ partials) {
   using DD = Dist<D>;
   if constexpr (uses_log_table<DD>::value) log_table_init();
+  if constexpr (use_tab_body<DD, FN>()) phi_table_init();
   const long long ntiles = n / kTile;
   double acc = 0.0;
   if constexpr (!REDUCE && IO == 2 && FN == M355_LOGPDF && has_f32_body<DD>::value) {
@@ -199,8 +213,8 @@ M355_DEV void scalar_body(const void* __restrict__ x, int xdt, void* __restrict_
     for (int u = 0; u < kUnroll; ++u) load2<IO>(x, xdt, base + u * (kBlock * kVec), v[u][0], v[u][1]);
 #pragma unroll
     for (int u = 0; u < kUnroll; ++u) {
-      v[u][0] = DD::template eval<FN>(v[u][0], k);
-      v[u][1] = DD::template eval<FN>(v[u][1], k);
+      v[u][0] = eval_scalar<DD, FN>(v[u][0], k);
+      v[u][1] = eval_scalar<DD, FN>(v[u][1], k);
       if constexpr (REDUCE) {
         acc += v[u][0] + v[u][1];
       } else {
@@ -210,7 +224,7 @@ M355_DEV void scalar_body(const void* __restrict__ x, int xdt, void* __restrict_
   }
   for (long long i = ntiles * kTile + (long long)blockIdx.x * kBlock + threadIdx.x; i < n;
        i += (long long)gridDim.x * kBlock) {
-    const double r = DD::template eval<FN>(load1(x, xdt, i), k);
+    const double r = eval_scalar<DD, FN>(load1(x, xdt, i), k);
     if constexpr (REDUCE) acc += r;
     else store1(out, odt, i, r);
   }

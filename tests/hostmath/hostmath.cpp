@@ -74,6 +74,7 @@ extern "C" int hm_sum_acc(int dist, long n, const double* x, const double* p, do
 
 extern "C" void hm_log(long n, const double* x, double* out) { for (long i = 0; i < n; ++i) out[i] = flog(x[i]); }
 extern "C" void hm_log1p(long n, const double* x, double* out) { for (long i = 0; i < n; ++i) out[i] = flog1p(x[i]); }
+extern "C" void hm_logphi_tab(long n, const double* x, double* out) { for (long i = 0; i < n; ++i) out[i] = normal_logcdf_z_tab(x[i]); }
 extern "C" void hm_erfcx(long n, const double* x, double* out) { for (long i = 0; i < n; ++i) out[i] = erfcx_(x[i]); }
 extern "C" void hm_erfinv(long n, const double* x, double* out) { for (long i = 0; i < n; ++i) out[i] = erfinv_(x[i]); }
 extern "C" void hm_gammainc(long n, const double* a, const double* x, double* out) {

@@ -268,7 +268,10 @@ def test_studentt_large_nu_arm(gpu):
                 ok = H.close(got, exp)
                 assert np.all(ok), (nu, fn, x[~ok][:4], got[~ok][:4], exp[~ok][:4])
         # the arm really is the mis-imported one, and the boundary nu = 1e5 itself is on the exact-formula side
-        assert np.array_equal(studentt.logpdf(x, nu, mu, sigma), normal.logcdf(x, mu, sigma))
+        # (normal's own scalar-parameter kernel reads log Phi from its LDS table, the arm inside studentt's kernel
+        # evaluates the erfcx form: the same function to 1e-15, no longer the same bits)
+        a, b = studentt.logpdf(x, nu, mu, sigma), normal.logcdf(x, mu, sigma)
+        assert np.all((a == b) | (np.abs(a - b) <= 2e-15 * np.maximum(1.0, np.abs(b))))
         assert np.array_equal(studentt.logcdf(x, nu, mu, sigma), normal.cdf((x - mu) / sigma, mu, sigma))
     # nu = 1e5 itself is on the exact-formula side.  There gammaln((nu+1)/2) - gammaln(nu/2) subtracts two values of
     # 4.9e5: one ulp of either is 5.8e-11 on the result in the reference itself (measured against mpmath: SciPy's

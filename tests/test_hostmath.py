@@ -132,6 +132,27 @@ def test_host_erfcx_erfinv(hostlib):
     assert np.array_equal(np.isnan(got), np.isnan(exp))  # |x| > 1 and NaN
 
 
+def test_host_logphi_table(hostlib):
+    """normal_logcdf_z_tab (piecewise degree-8 polynomials on [-10, 6), the exact body outside): against mpmath at
+    4e-16 max(1, |log Phi|) on the table's range, cell boundaries and both ends included, and against SciPy's log_ndtr
+    at 1e-13 everywhere (NaN, infinities and the far tails go through normal_logcdf_z)."""
+    import mpmath as mp
+    from scipy.special import log_ndtr
+
+    rng = np.random.default_rng(17)
+    edges = -10.0 + np.arange(0, 257) / 16.0
+    z = np.concatenate([rng.uniform(-10, 6, 4000), edges, np.nextafter(edges, -np.inf), np.nextafter(edges, np.inf)])
+    got = vec(hostlib, "hm_logphi_tab", z)
+    mp.mp.dps = 40
+    for zi, gi in zip(z, got):
+        ref = mp.log(mp.ncdf(mp.mpf(zi)))
+        assert abs(gi - ref) <= 4e-16 * max(1, abs(ref)), (zi, gi, float(ref))
+    z = np.concatenate([rng.normal(0, 6, 200000), [-40.0, -10.0, 6.0, 38.0, np.inf, -np.inf, np.nan, 0.0, -0.0]])
+    got, exp = vec(hostlib, "hm_logphi_tab", z), log_ndtr(z)
+    ok = (got == exp) | (np.isnan(got) & np.isnan(exp)) | (np.abs(got - exp) <= 1e-13 * np.maximum(1.0, np.abs(exp)))
+    assert np.all(ok), (z[~ok][:5], got[~ok][:5], exp[~ok][:5])
+
+
 def test_host_sincos_2pi_and_u53(hostlib):
     """The Box-Muller angle (two degree-7 polynomials after an exact reduction of 4u) against numpy at 1e-15, exact at
     the quadrant points; u53 stays strictly inside (0, 1) at both ends of its 52-bit range."""
