@@ -229,6 +229,12 @@ extern "C" {
 
 int64_t m355_sumlogp_static_max_n(void) { return M355_SUMLOGP_STATIC_MAX_N; }
 
+int64_t m355_set_tab_min_n(int64_t min_n) {
+  const int64_t old = m355::tab_min_n_ref();
+  m355::tab_min_n_ref() = min_n < 0 ? m355::kTabMinN : (long long)min_n;
+  return old;
+}
+
 int m355_sumlogp_static(int dist, int fn, int64_t n, const m355_operand* x, int nparams, const m355_operand* params,
                         double* out_sum, void* stream) {
   if (n > M355_SUMLOGP_STATIC_MAX_N)

@@ -138,7 +138,7 @@ template <> struct Dist<M355_GAMMA> {
   static constexpr int NP = 2;
   static constexpr bool kLogTable = true;  // logpdf uses flog_tab
   struct K {
-    double alpha, beta, am1, c, lga;
+    double alpha, beta, am1, c, lga, tsc;  // tsc: 2^-e with 2^e ~ alpha / beta (k_tab's variable is log(x tsc))
   };
   static M355_HD K derive(const double* p) {
     K k;
@@ -147,8 +147,19 @@ template <> struct Dist<M355_GAMMA> {
     k.am1 = p[0] - 1.0;
     k.lga = lgamma_(p[0]);
     k.c = p[0] * flog(p[1]) - k.lga;
+    const double mean = p[0] / p[1];
+    const int e = (mean > 0x1p-900 && mean < 0x1p900) ? hw_frexp_exp(mean) : 0;
+    k.tsc = __builtin_bit_cast(double, (unsigned long long)(1023 - e) << 52);
     return k;
   }
+  // k_tab (m355_elemwise.h): the cdf family is tabulated in w = log x.  Shapes below 1 are left to the exact kernels:
+  // their lower quantiles sit at x ~ 1e-9^(1/alpha) and 64 cells across that range are too wide for the bulk.
+  // Very large shapes neither: the exact bodies' own noise (~1e-16 alpha) then exceeds what a cell must show to be used.
+  static bool tab_ok(const K& k) { return k.alpha >= 1.0 && k.alpha <= 1e4 && k.beta > 0.0 && k.beta < kInf; }
+  // (x is scaled by a power of two near beta / alpha first, so that |w| stays of the order of the spread of log x: for
+  // large alpha the function is steep in w -- d log P / dw ~ sqrt(alpha) -- and log x itself would carry |log x| ulps)
+  static M355_DEV double tab_w(double x, const K& k) { return flog_tab_or_nan(x * k.tsc); }
+  static M355_DEV double tab_x(double w, const K& k) { return fdiv(exp_(w), k.tsc); }
   // gamma.py:77-82 with (alpha-1)*log(x) as xlogy0 (quirk Q2).
   static M355_DEV double logpdf(double x, const K& k) {
     const double t = xlogy0_l(k.am1, flog_tab(x));
@@ -238,6 +249,10 @@ template <> struct Dist<M355_BETA> {
     return k;
   }
   // beta.py:102-108; xlogy0(alpha+beta-1, 1) is a*log(1) == 0 (or the xlogy0 zero).
+  // k_tab: the cdf family is tabulated in w = logit x (1 - x is exact for x >= 1/2); shapes below 1 as for gamma
+  static bool tab_ok(const K& k) { return k.a >= 1.0 && k.b >= 1.0 && k.a + k.b <= 500.0; }
+  static M355_DEV double tab_w(double x, const K&) { return flog_tab_or_nan(fdiv_t<1, true>(x, 1.0 - x)); }
+  static M355_DEV double tab_x(double w, const K&) { return fdiv(1.0, 1.0 + exp_(-w)); }
   static M355_DEV double logpdf(double x, const K& k) {
     const double t = xlogy0_l(k.am1, flog_tab(x)) + xlogy0_l(k.bm1, flog_tab(1.0 - x));
     const double r = t - (0.0 + k.lbeta);
@@ -342,6 +357,8 @@ template <> struct Dist<M355_STUDENTT> {
     k.ihalf_h = betainc_half(0.5 * p[0], 0.5, k.lbeta_h);
     return k;
   }
+  // (No k_tab for studentt: the reference's cdf takes betainc at nu / (z^2 + nu), which rounds for small |z| -- its values
+  // near the centre carry a staircase of up to 1e-8 / |z| ulps that the exact body reproduces and a smooth table cannot.)
   // studentt.py:108-119.  The nu > 1e5 arm is normal.LOGCDF(x, mu, sigma): the reference binds
   // `normal_logpdf` to normal.logcdf (studentt.py:8); reproduced as is (quirk Q1).
   static M355_DEV double logpdf(double x, const K& k) {

@@ -796,6 +796,182 @@ template <class T, int FN> constexpr bool bin_this() {
   return (m == 1 && FN != M355_LOGPDF && FN != M355_PDF) || (m == 2 && (FN == M355_PPF || FN == M355_ISF));
 }
 
+// ---- Per-launch tabulation (scalar parameters, large n) ---------------------------------------------------------------
+// With the parameters fixed, logcdf / logsf / cdf / sf are smooth functions of ONE variable, and the exact bodies cost
+// 400-800 operations per element behind divergent loops.  k_tab has every workgroup tabulate the function once --
+// kTabCells cells across [ppf(1e-9), ppf(1 - 1e-9)] in a variable w = Dist<>::tab_w(x) in which the function is tame
+// (log x for gamma, logit x for beta, asinh z for studentt), a degree-15 Chebyshev interpolant per cell from 16 exact
+// evaluations at its Chebyshev nodes (1024 evaluations per workgroup, four per thread) -- and then evaluates its
+// elements from LDS: the coefficients are converted to the monomial basis in the cell's t in [-1, 1) -- safe because a
+// validated cell's Chebyshev coefficients decay by >= 8.6x per degree, so each monomial coefficient is dominated by its
+// own Chebyshev term -- and a lookup is one table logarithm, the cell arithmetic, eight 16-byte LDS reads and a
+// degree-15 Horner chain.
+// Every cell is validated: its last two coefficients must be below 1e-14 of its scale (they measure both the
+// truncation and any noise in the node values, e.g. from a badly conditioned x(w)); a cell that fails is poisoned with
+// NaN.  An element whose table value is NaN -- poisoned cell, w outside the table, NaN input -- takes the exact body.
+// So the table can only replace the exact value where it has shown itself converged; the price of a miss is divergence.
+constexpr int kTabCells = 64, kTabN = 16, kTabStride = 18;
+constexpr double kTabTailQ = 1e-9;     // the table spans the quantiles [kTabTailQ, 1 - kTabTailQ]
+constexpr double kTabCoefTol = 1e-14;  // |c_14| + |c_15| <= kTabCoefTol * max(1, |c_0|)
+template <class T, class = void> struct has_tab_var : std::false_type {};
+template <class T> struct has_tab_var<T, std::void_t<decltype(&T::tab_w)>> : std::true_type {};
+template <class DD, int FN> constexpr bool tab_this() {
+  return has_tab_var<DD>::value && (FN == M355_LOGCDF || FN == M355_LOGSF || FN == M355_CDF || FN == M355_SF);
+}
+// cos(pi a / 32), a = 0 .. 63: the Chebyshev nodes of a cell are the odd entries, cos(pi m (q + 1/2) / 16) = entry m (2q + 1) mod 64
+constexpr double kCos32[64] = {
+    0x1.0000000000000p+0, 0x1.fd88da3d12526p-1, 0x1.f6297cff75cb0p-1, 0x1.e9f4156c62ddap-1,
+    0x1.d906bcf328d46p-1, 0x1.c38b2f180bdb1p-1, 0x1.a9b66290ea1a3p-1, 0x1.8bc806b151741p-1,
+    0x1.6a09e667f3bcdp-1, 0x1.44cf325091dd6p-1, 0x1.1c73b39ae68c8p-1, 0x1.e2b5d3806f63bp-2,
+    0x1.87de2a6aea963p-2, 0x1.294062ed59f06p-2, 0x1.8f8b83c69a60bp-3, 0x1.917a6bc29b42cp-4,
+    0.0, -0x1.917a6bc29b42cp-4, -0x1.8f8b83c69a60bp-3, -0x1.294062ed59f06p-2,
+    -0x1.87de2a6aea963p-2, -0x1.e2b5d3806f63bp-2, -0x1.1c73b39ae68c8p-1, -0x1.44cf325091dd6p-1,
+    -0x1.6a09e667f3bcdp-1, -0x1.8bc806b151741p-1, -0x1.a9b66290ea1a3p-1, -0x1.c38b2f180bdb1p-1,
+    -0x1.d906bcf328d46p-1, -0x1.e9f4156c62ddap-1, -0x1.f6297cff75cb0p-1, -0x1.fd88da3d12526p-1,
+    -0x1.0000000000000p+0, -0x1.fd88da3d12526p-1, -0x1.f6297cff75cb0p-1, -0x1.e9f4156c62ddap-1,
+    -0x1.d906bcf328d46p-1, -0x1.c38b2f180bdb1p-1, -0x1.a9b66290ea1a3p-1, -0x1.8bc806b151741p-1,
+    -0x1.6a09e667f3bcdp-1, -0x1.44cf325091dd6p-1, -0x1.1c73b39ae68c8p-1, -0x1.e2b5d3806f63bp-2,
+    -0x1.87de2a6aea963p-2, -0x1.294062ed59f06p-2, -0x1.8f8b83c69a60bp-3, -0x1.917a6bc29b42cp-4,
+    0.0, 0x1.917a6bc29b42cp-4, 0x1.8f8b83c69a60bp-3, 0x1.294062ed59f06p-2,
+    0x1.87de2a6aea963p-2, 0x1.e2b5d3806f63bp-2, 0x1.1c73b39ae68c8p-1, 0x1.44cf325091dd6p-1,
+    0x1.6a09e667f3bcdp-1, 0x1.8bc806b151741p-1, 0x1.a9b66290ea1a3p-1, 0x1.c38b2f180bdb1p-1,
+    0x1.d906bcf328d46p-1, 0x1.e9f4156c62ddap-1, 0x1.f6297cff75cb0p-1, 0x1.fd88da3d12526p-1};
+
+// T_k(t) = sum_j t[k][j] t^j, k, j < 16 (integers up to 2^14: exact)
+struct ChebMono16 {
+  double t[16][16];
+  constexpr ChebMono16() : t{} {
+    t[0][0] = 1.0;
+    t[1][1] = 1.0;
+    for (int k = 2; k < 16; ++k)
+      for (int j = 0; j < 16; ++j) t[k][j] = (j > 0 ? 2.0 * t[k - 1][j - 1] : 0.0) - t[k - 2][j];
+  }
+};
+constexpr ChebMono16 kChebMono16{};
+
+template <int D, int FN> __device__ __noinline__ double tab_exact(double x, const typename Dist<D>::K& k) {
+  return Dist<D>::template eval<FN>(x, k);
+}
+
+template <int D, int FN, bool F64IO>
+__global__ __launch_bounds__(kBlock) void k_tab(const void* __restrict__ x, int xdt, void* __restrict__ out, int odt,
+                                                long long n, const typename Dist<D>::K k) {
+  using DD = Dist<D>;
+  constexpr int IO = F64IO ? 1 : 0;
+  // cell stride 18 doubles = 144 B: with 128 B every cell would start in the same LDS bank and lanes in different cells
+  // would serialise
+  __shared__ __attribute__((aligned(16))) double coef[kTabCells * kTabStride];
+  __shared__ double cosv[64];
+  __shared__ double tm[kTabN * kTabN];
+  __shared__ int bad[kTabCells];
+  __shared__ double rng[2];
+  log_table_init();  // tab_w may use flog_tab
+  if (threadIdx.x < 2) {
+    const double xe = DD::template eval<M355_PPF>(threadIdx.x == 0 ? kTabTailQ : 1.0 - kTabTailQ, k);
+    rng[threadIdx.x] = DD::tab_w(xe, k);
+  }
+  if (threadIdx.x < 64) cosv[threadIdx.x] = kCos32[threadIdx.x];
+  tm[threadIdx.x] = kChebMono16.t[threadIdx.x >> 4][threadIdx.x & 15];  // (kBlock == 256 entries)
+  __syncthreads();
+  const double wlo = rng[0], whi = rng[1];
+  const double h = (whi - wlo) * (1.0 / kTabCells);
+  const double inv_h = (h > 0.0) ? 1.0 / h : kNaN;  // (an empty or NaN range poisons every lookup)
+  // node values: thread t takes (cell, node) = (j >> 4, j & 15) for j = t, t + 256, ...
+  for (int j = threadIdx.x; j < kTabCells * kTabN; j += kBlock) {
+    const double w = wlo + h * ((double)(j >> 4) + 0.5 + 0.5 * cosv[2 * (j & 15) + 1]);
+    coef[(j >> 4) * kTabStride + (j & 15)] = DD::template eval<FN>(DD::tab_x(w, k), k);
+  }
+  __syncthreads();
+  // Chebyshev coefficients of each cell: c_m = (2 / 16) sum_j f_j cos(pi m (j + 1/2) / 16), c_0 halved
+  double cm[kTabCells * kTabN / kBlock];
+#pragma unroll
+  for (int r = 0; r < kTabCells * kTabN / kBlock; ++r) {
+    const int j = threadIdx.x + r * kBlock, cell = j >> 4, m = j & 15;
+    double acc = 0.0;
+#pragma unroll
+    for (int q = 0; q < kTabN; ++q) {
+      acc = __builtin_fma(coef[cell * kTabStride + q], cosv[(m * (2 * q + 1)) & 63], acc);
+    }
+    cm[r] = acc * (m == 0 ? 1.0 / 16.0 : 2.0 / 16.0);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < kTabCells * kTabN / kBlock; ++r) {
+    const int j = threadIdx.x + r * kBlock;
+    coef[(j >> 4) * kTabStride + (j & 15)] = cm[r];
+  }
+  __syncthreads();
+  if (threadIdx.x < kTabCells) {
+    const double* c = coef + threadIdx.x * kTabStride;
+    const double scale = __builtin_fabs(c[0]) > 1.0 ? __builtin_fabs(c[0]) : 1.0;
+    const double tail = __builtin_fabs(c[14]) + __builtin_fabs(c[15]);
+    bad[threadIdx.x] = !(tail <= kTabCoefTol * scale);  // NaN / inf coefficients are bad too
+  }
+  // monomial coefficients a_j = sum_k c_k T_k[j]
+#pragma unroll
+  for (int r = 0; r < kTabCells * kTabN / kBlock; ++r) {
+    const int j = threadIdx.x + r * kBlock, cell = j >> 4, m = j & 15;
+    double acc = 0.0;
+#pragma unroll
+    for (int q = 0; q < kTabN; ++q) acc = __builtin_fma(coef[cell * kTabStride + q], tm[q * kTabN + m], acc);
+    cm[r] = acc;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < kTabCells * kTabN / kBlock; ++r) {
+    const int j = threadIdx.x + r * kBlock;
+    coef[(j >> 4) * kTabStride + (j & 15)] = ((j & 15) == 0 && bad[j >> 4]) ? kNaN : cm[r];
+  }
+  __syncthreads();
+  // table value, NaN where the table has nothing to say (w outside it, a poisoned cell, a NaN argument)
+  auto lookup = [&](double xv) -> double {
+    const double s = (DD::tab_w(xv, k) - wlo) * inv_h;
+    const double fi = __builtin_floor(s);
+    const bool in = (s >= 0.0) & (s < (double)kTabCells);
+    const double t = __builtin_fma(2.0, s - fi, -1.0);
+    const d2_t* c = reinterpret_cast<const d2_t*>(coef + (in ? (int)fi : 0) * kTabStride);
+    d2_t cc = c[kTabN / 2 - 1];
+    double r = __builtin_fma(cc.y, t, cc.x);
+#pragma unroll
+    for (int q = kTabN / 2 - 2; q >= 0; --q) {
+      cc = c[q];  // a_{2q}, a_{2q+1}
+      r = __builtin_fma(__builtin_fma(r, t, cc.y), t, cc.x);
+    }
+    return in ? r : kNaN;
+  };
+  const long long ntiles = n / kTile;
+  for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const long long base = tile * kTile + threadIdx.x * kVec;
+    double v[kUnroll][kVec], r[kUnroll][kVec];
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) load2<IO>(x, xdt, base + u * (kBlock * kVec), v[u][0], v[u][1]);
+    bool miss = false;
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) {
+#pragma unroll
+      for (int q = 0; q < kVec; ++q) {
+        r[u][q] = lookup(v[u][q]);
+        miss |= r[u][q] != r[u][q];
+      }
+    }
+    if (miss) {  // rare: one out-of-line copy of the exact body serves all four slots
+#pragma unroll 1
+      for (int e = 0; e < kUnroll * kVec; ++e) {
+        const double rv = r[e / kVec][e % kVec];
+        if (rv != rv) r[e / kVec][e % kVec] = tab_exact<D, FN>(v[e / kVec][e % kVec], k);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) store2<IO>(out, odt, base + u * (kBlock * kVec), r[u][0], r[u][1]);
+  }
+  for (long long i = ntiles * kTile + (long long)blockIdx.x * kBlock + threadIdx.x; i < n; i += (long long)gridDim.x * kBlock) {
+    const double xv = load1(x, xdt, i);
+    double rv = lookup(xv);
+    if (rv != rv) rv = tab_exact<D, FN>(xv, k);
+    store1(out, odt, i, rv);
+  }
+}
+
 struct GenericOps {
   DevOperand x;
   DevOperand p[kMaxParams];
@@ -842,6 +1018,17 @@ __global__ __launch_bounds__(kBlock) void k_generic(GenericOps ops, void* __rest
 // with a one-entry table (derived once per workgroup) instead of being derived on the host.
 template <class T, class = void> struct device_derive : std::false_type {};
 template <class T> struct device_derive<T, std::void_t<decltype(T::kDeviceDerive)>> : std::true_type {};
+
+// k_tab's launch: four workgroups per CU (each builds the table: 1024 exact evaluations), from kTabMinN elements
+// (below, building 1024 tables costs more than evaluating the elements exactly); m355_set_tab_min_n() moves the
+// threshold (tests force the table onto small inputs; a huge value switches it off).
+constexpr int kTabBlocks = 1024;
+constexpr long long kTabMinN = 1ll << 21;
+inline long long& tab_min_n_ref() {
+  static long long v = [] { const char* e = getenv("M355_TAB_MIN_N"); return e ? atoll(e) : kTabMinN; }();  // (test runs)
+  return v;
+}
+inline long long tab_min_n() { return tab_min_n_ref(); }
 
 // M355_NO_BINNING=1 in the environment sends the divergent functions through k_scalar (A/B measurements)
 inline bool binning_disabled() {
@@ -908,6 +1095,21 @@ template <int D, int FN, bool REDUCE> int launch_fn(const LaunchArgs& a) {
       // parameter-only constants once, on the host; they reach the kernel as arguments (SGPRs)
       const double pp[kMaxParams] = {a.p[0].scalar, a.p[1].scalar, a.p[2].scalar, a.p[3].scalar};
       const typename DD::K k = DD::derive(pp);
+      if constexpr (!REDUCE && tab_this<DD, FN>()) {
+        if (n >= tab_min_n() && DD::tab_ok(k) && !binning_disabled()) {
+          const long long want = tiles < 1 ? 1 : tiles;
+          static const int tb = [] { const char* e = getenv("M355_TAB_BLOCKS"); return e ? atoi(e) : kTabBlocks; }();
+          const int bb = (int)(want > tb ? tb : want);
+          if (a.x.dtype == M355_F64 && a.out_dtype == M355_F64) {  // (cdf / sf too: kFastIO is k_scalar's economy)
+            hipLaunchKernelGGL((k_tab<D, FN, true>), dim3(bb), dim3(kBlock), 0, a.stream, a.x.ptr, a.x.dtype, a.out,
+                               a.out_dtype, n, k);
+          } else {
+            hipLaunchKernelGGL((k_tab<D, FN, false>), dim3(bb), dim3(kBlock), 0, a.stream, a.x.ptr, a.x.dtype, a.out,
+                               a.out_dtype, n, k);
+          }
+          return (int)hipGetLastError();
+        }
+      }
       if constexpr (!REDUCE && bin_this<DD, FN>()) {
         if (n >= (long long)kBinMinTiles * kBinTile && !binning_disabled()) {
           const long long bt = n / kBinTile;

@@ -245,6 +245,30 @@ M355_HD double flog_tab(double x) {
   res = res + log_c;
   return __builtin_fma(ef, sconst(kLn2Hi), res);
 }
+// flog_tab without its branch: NaN for every argument flog_tab hands to flog (x <= 0, subnormal, inf, NaN).  For
+// callers that treat those as misses anyway (k_tab's table variable).
+M355_HD double flog_tab_or_nan(double x) {
+  const unsigned long long bits = __builtin_bit_cast(unsigned long long, x);
+  unsigned hx = (unsigned)(bits >> 32);
+  const bool exc = (hx - 0x00100000u) >= 0x7fe00000u;
+  hx += 0x3ff00000u - 0x3fe6a09eu;
+  const int k = (int)(hx >> 20) - 0x3ff;
+  const unsigned frac = hx & 0x000fffffu;
+  const double m = __builtin_bit_cast(double, ((unsigned long long)(frac + 0x3fe6a09eu) << 32) | (bits & 0xffffffffull));
+  double inv_c, log_c;
+  log_table_fetch(frac >> 12, inv_c, log_c);
+  const double r = __builtin_fma(m, inv_c, -1.0);
+  double p = sconst(0.2);
+  p = __builtin_fma(-p, r, sconst(0.25));
+  p = __builtin_fma(-p, r, sconst(0x1.5555555555555p-2));
+  p = __builtin_fma(-p, r, sconst(0.5));
+  const double l1p = __builtin_fma(-(r * r), p, r);
+  const double ef = (double)k;
+  double res = __builtin_fma(ef, sconst(kLn2Lo), l1p);
+  res = res + log_c;
+  res = __builtin_fma(ef, sconst(kLn2Hi), res);
+  return exc ? kNaN : res;
+}
 // log(1 + w), w > -1, on the table log (same correction as flog1p_stream; for w < 0 the sum 1 + w is exact
 // below -1/2 and the first-order correction c (2 - u) ~ c / u holds to 3e-17 above it)
 M355_HD double flog1p_tab(double w) {

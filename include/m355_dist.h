@@ -140,6 +140,15 @@ int m355_elemwise(int dist, int fn, int out_dtype, int64_t n, const m355_operand
                   const m355_operand* params, void* out, void* stream);
 
 /*
+ * Tuning knob of m355_elemwise, no counterpart in the reference.  With scalar parameters and at least `min_n`
+ * elements, logcdf / logsf / cdf / sf of gamma, beta and studentt are evaluated from a table that every workgroup
+ * builds from the exact bodies at launch (k_tab; cells that do not reach 1e-14 and arguments
+ * outside the table take the exact body).  Returns the previous threshold; min_n < 0 restores the default (2^21),
+ * INT64_MAX switches the table off.  Process-wide, not synchronised with launches in flight on other threads.
+ */
+int64_t m355_set_tab_min_n(int64_t min_n);
+
+/*
  * *out_sum = sum_i fn_dist(x[i], params...) in float64: replaces `pt.sum(<dist>.logpdf(...))`
  * (no function of its own in the reference) without materialising the
  * elementwise result.  Deterministic: per-thread partial sums -> wavefront shuffle reduction ->

@@ -396,6 +396,59 @@ def test_binomial_logpmf_large_counts(gpu, n, p):
             assert abs(gi - ref) <= 1e-12 * max(1.0, abs(ref)) + 4 * 2.3e-16 * float(gammaln(n + 1.0)), (n, p, xi)
 
 
+@pytest.mark.parametrize("name, params", [("gamma", (2.5, 1.3)), ("gamma", (1.0, 0.2)), ("gamma", (400.0, 2.0)),
+                                          ("gamma", (8e3, 1e-3)), ("beta", (2.0, 5.0)), ("beta", (1.0, 1.0)),
+                                          ("beta", (60.0, 1.5)), ("beta", (150.0, 300.0)), ("gamma", (0.3, 1.0)),
+                                          ("beta", (0.5, 0.5)), ("gamma", (3e5, 1e-3)), ("beta", (300.0, 800.0))])
+def test_tabulated_kernel(gpu, name, params):
+    """k_tab (per-launch Chebyshev tables of logcdf / logsf / cdf / sf for scalar parameters, m355_elemwise.h), forced
+    onto a small input through m355_set_tab_min_n: against the oracle at the parity bar and against the exact kernels at
+    5e-13 max(1, |b|) (the exact bodies' own noise at large parameters is what the table smooths); the special values (NaN, infinities, the support's ends, points outside it, the far tails beyond
+    the table) must come out as the exact kernels give them, bit for bit; shapes below 1 and very large ones are not
+    tabulated at all (Dist<>::tab_ok)."""
+    from distributions_amd import _lib
+
+    L = _lib.lib()
+    nan, inf = np.nan, np.inf
+    rng = np.random.default_rng(33)
+    m = mod(name)
+    n = 40_000 + 37  # not a multiple of the tile
+    if name == "gamma":
+        x = rng.gamma(params[0], 1.0 / params[1], n)
+        special = np.array([nan, inf, -inf, 0.0, -1.0, 5e-324, 1e-300, 1e300, x.min() * 1e-6, x.max() * 30])
+    else:
+        x = rng.beta(params[0], params[1], n)
+        special = np.array([nan, inf, -inf, 0.0, 1.0, -0.5, 1.5, 5e-324, 1e-300, 1 - 2.0**-20, x.min() * 1e-6])
+    x[: special.size] = special
+    if name == "gamma":
+        tabulated = 1.0 <= params[0] <= 1e4
+    else:
+        tabulated = min(params) >= 1.0 and sum(params) <= 500.0
+    for fn in ("logcdf", "logsf", "cdf", "sf"):
+        old = L.m355_set_tab_min_n(2**62)
+        try:
+            exact = getattr(m, fn)(x, *params)
+            L.m355_set_tab_min_n(1)
+            tab = getattr(m, fn)(x, *params)
+        finally:
+            L.m355_set_tab_min_n(old)
+        with np.errstate(all="ignore"):
+            exp = R.TABLE[f"{name}_{fn}"](x, *params)
+        assert np.array_equal(np.isnan(tab), np.isnan(exact))
+        sp_ = slice(0, 7)  # NaN, infinities, the ends of the support, points outside it
+        assert np.array_equal(tab[sp_], exact[sp_], equal_nan=True), (fn, x[sp_], tab[sp_], exact[sp_])
+        if tabulated:  # (the exact kernels' own parity is the business of the tests above)
+            ok = H.close(tab, exp) | H.family_ok(name, fn, tab, exp, params)
+            assert np.all(ok), (name, fn, params, x[~ok][:4], tab[~ok][:4], exp[~ok][:4])
+        fin = np.isfinite(exact)
+        assert np.all(np.abs(tab[fin] - exact[fin]) <= 5e-13 * np.maximum(1.0, np.abs(exact[fin])))
+        if tabulated:
+            assert np.mean(tab == exact) < 0.5  # the table really was used
+        else:
+            assert np.array_equal(tab, exact, equal_nan=True)
+    assert L.m355_set_tab_min_n(-1) == old and L.m355_set_tab_min_n(old) == 2**21
+
+
 @pytest.mark.parametrize("h, z", H.POLYAGAMMA_CASES)
 def test_polyagamma(gpu, h, z):
     """polyagamma: no SciPy counterpart -- every function against the oracle (series density,
