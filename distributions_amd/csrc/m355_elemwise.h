@@ -816,8 +816,15 @@ constexpr double kTabCoefTol = 1e-14;  // |c_14| + |c_15| <= kTabCoefTol * max(1
 template <class T, class = void> struct has_tab_var : std::false_type {};
 template <class T> struct has_tab_var<T, std::void_t<decltype(&T::tab_w)>> : std::true_type {};
 template <class DD, int FN> constexpr bool tab_this() {
-  return has_tab_var<DD>::value && (FN == M355_LOGCDF || FN == M355_LOGSF || FN == M355_CDF || FN == M355_SF);
+  return has_tab_var<DD>::value && (FN == M355_LOGCDF || FN == M355_LOGSF || FN == M355_CDF || FN == M355_SF ||
+                                    FN == M355_PPF || FN == M355_ISF);
 }
+// Quantiles are tabulated in w = logit(q) over q in [kTabTailQ, 1 - kTabTailQ]: ppf(sigmoid(w)) is analytic in the strip
+// |Im w| < pi, and 64 cells of 0.65 converge like 0.1^n.  A node with w > 0 cannot be computed as ppf(q): q = 1 - p
+// rounds where p = sigmoid(-w) does not, so it takes ppf(fl(1 - p)) as a start and two Newton steps on
+// logsf(x) = log p, which holds its relative accuracy in the tail.  isf(q) is the reference's ppf(1 - q) with the
+// rounded 1 - q (e.g. gamma.py:57-58), so it looks up qq = fl(1 - q) -- the same staircase as the exact kernel.
+constexpr double kTabLogitMax = 20.723265835946928;  // logit(1 - 1e-9)
 // cos(pi a / 32), a = 0 .. 63: the Chebyshev nodes of a cell are the odd entries, cos(pi m (q + 1/2) / 16) = entry m (2q + 1) mod 64
 constexpr double kCos32[64] = {
     0x1.0000000000000p+0, 0x1.fd88da3d12526p-1, 0x1.f6297cff75cb0p-1, 0x1.e9f4156c62ddap-1,
@@ -865,10 +872,15 @@ __global__ __launch_bounds__(kBlock) void k_tab(const void* __restrict__ x, int 
   __shared__ double tm[kTabN * kTabN];
   __shared__ int bad[kTabCells];
   __shared__ double rng[2];
+  constexpr bool QDOM = FN == M355_PPF || FN == M355_ISF;
   log_table_init();  // tab_w may use flog_tab
   if (threadIdx.x < 2) {
-    const double xe = DD::template eval<M355_PPF>(threadIdx.x == 0 ? kTabTailQ : 1.0 - kTabTailQ, k);
-    rng[threadIdx.x] = DD::tab_w(xe, k);
+    if constexpr (QDOM) {
+      rng[threadIdx.x] = threadIdx.x == 0 ? -kTabLogitMax : kTabLogitMax;
+    } else {
+      const double xe = DD::template eval<M355_PPF>(threadIdx.x == 0 ? kTabTailQ : 1.0 - kTabTailQ, k);
+      rng[threadIdx.x] = DD::tab_w(xe, k);
+    }
   }
   if (threadIdx.x < 64) cosv[threadIdx.x] = kCos32[threadIdx.x];
   tm[threadIdx.x] = kChebMono16.t[threadIdx.x >> 4][threadIdx.x & 15];  // (kBlock == 256 entries)
@@ -879,7 +891,26 @@ __global__ __launch_bounds__(kBlock) void k_tab(const void* __restrict__ x, int 
   // node values: thread t takes (cell, node) = (j >> 4, j & 15) for j = t, t + 256, ...
   for (int j = threadIdx.x; j < kTabCells * kTabN; j += kBlock) {
     const double w = wlo + h * ((double)(j >> 4) + 0.5 + 0.5 * cosv[2 * (j & 15) + 1]);
-    coef[(j >> 4) * kTabStride + (j & 15)] = DD::template eval<FN>(DD::tab_x(w, k), k);
+    double f;
+    if constexpr (QDOM) {
+      const double e = exp_(-__builtin_fabs(w));
+      const double p = fdiv(e, 1.0 + e);  // the smaller of q, 1 - q
+      if (w <= 0.0) {
+        f = DD::template eval<M355_PPF>(p, k);
+      } else {
+        f = DD::template eval<M355_PPF>(1.0 - p, k);
+        const double lp = flog(p);
+#pragma unroll 1
+        for (int it = 0; it < 2; ++it) {
+          const double lsf = DD::template eval<M355_LOGSF>(f, k);
+          const double step = (lsf - lp) * exp_(lsf - DD::template eval<M355_LOGPDF>(f, k));
+          if (step - step == 0.0) f += step;
+        }
+      }
+    } else {
+      f = DD::template eval<FN>(DD::tab_x(w, k), k);
+    }
+    coef[(j >> 4) * kTabStride + (j & 15)] = f;
   }
   __syncthreads();
   // Chebyshev coefficients of each cell: c_m = (2 / 16) sum_j f_j cos(pi m (j + 1/2) / 16), c_0 halved
@@ -903,7 +934,8 @@ __global__ __launch_bounds__(kBlock) void k_tab(const void* __restrict__ x, int 
   __syncthreads();
   if (threadIdx.x < kTabCells) {
     const double* c = coef + threadIdx.x * kTabStride;
-    const double scale = __builtin_fabs(c[0]) > 1.0 ? __builtin_fabs(c[0]) : 1.0;
+    // the parity bar is relative to max(1, |value|); a quantile must hold it relative to the root itself
+    const double scale = (QDOM || __builtin_fabs(c[0]) > 1.0) ? __builtin_fabs(c[0]) : 1.0;
     const double tail = __builtin_fabs(c[14]) + __builtin_fabs(c[15]);
     bad[threadIdx.x] = !(tail <= kTabCoefTol * scale);  // NaN / inf coefficients are bad too
   }
@@ -925,7 +957,14 @@ __global__ __launch_bounds__(kBlock) void k_tab(const void* __restrict__ x, int 
   __syncthreads();
   // table value, NaN where the table has nothing to say (w outside it, a poisoned cell, a NaN argument)
   auto lookup = [&](double xv) -> double {
-    const double s = (DD::tab_w(xv, k) - wlo) * inv_h;
+    double wv;
+    if constexpr (QDOM) {
+      const double qq = (FN == M355_ISF) ? 1.0 - xv : xv;
+      wv = flog_tab_or_nan(fdiv_t<1, true>(qq, 1.0 - qq));
+    } else {
+      wv = DD::tab_w(xv, k);
+    }
+    const double s = (wv - wlo) * inv_h;
     const double fi = __builtin_floor(s);
     const bool in = (s >= 0.0) & (s < (double)kTabCells);
     const double t = __builtin_fma(2.0, s - fi, -1.0);

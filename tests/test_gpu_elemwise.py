@@ -446,6 +446,33 @@ def test_tabulated_kernel(gpu, name, params):
             assert np.mean(tab == exact) < 0.5  # the table really was used
         else:
             assert np.array_equal(tab, exact, equal_nan=True)
+    # quantiles: tabulated in logit(q) over [1e-9, 1 - 1e-9]; beyond, q = 0, 1, NaN and q outside [0, 1] from the exact body
+    q = rng.uniform(0, 1, n)
+    q[:2000] = np.exp(rng.uniform(-20, 0, 2000))        # lower tail inside the table
+    q[2000:4000] = 1 - np.exp(rng.uniform(-20, 0, 2000))  # upper tail inside the table (1 - q exact)
+    specq = np.array([nan, 0.0, 1.0, -0.1, 1.1, 1e-300, 1e-12, 1 - 2.0**-53, 1 - 1e-12])
+    q[4000 : 4000 + specq.size] = specq
+    for fn in ("ppf", "isf"):
+        old = L.m355_set_tab_min_n(2**62)
+        try:
+            exact = getattr(m, fn)(q, *params)
+            L.m355_set_tab_min_n(1)
+            tab = getattr(m, fn)(q, *params)
+        finally:
+            L.m355_set_tab_min_n(old)
+        sp_ = slice(4000, 4000 + specq.size)
+        assert np.array_equal(tab[sp_], exact[sp_], equal_nan=True), (fn, specq, tab[sp_], exact[sp_])
+        assert np.array_equal(np.isnan(tab), np.isnan(exact))
+        fin = np.isfinite(exact)
+        assert np.all(np.abs(tab[fin] - exact[fin]) <= 2e-13 * np.abs(exact[fin])), fn
+        if tabulated:
+            with np.errstate(all="ignore"):
+                exp = R.TABLE[f"{name}_{fn}"](q, *params)
+            ok = H.ppf_close(name, fn, params, tab, exp) | H.ppf_unpinned(name, fn, q)
+            assert np.all(ok | ~np.isfinite(exp)), (name, fn, params, q[~ok][:4], tab[~ok][:4], exp[~ok][:4])
+            assert np.mean(tab == exact) < 0.5
+        else:
+            assert np.array_equal(tab, exact, equal_nan=True)
     assert L.m355_set_tab_min_n(-1) == old and L.m355_set_tab_min_n(old) == 2**21
 
 
