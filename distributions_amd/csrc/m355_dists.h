@@ -357,8 +357,51 @@ template <> struct Dist<M355_STUDENTT> {
     k.ihalf_h = betainc_half(0.5 * p[0], 0.5, k.lbeta_h);
     return k;
   }
-  // (No k_tab for studentt: the reference's cdf takes betainc at nu / (z^2 + nu), which rounds for small |z| -- its values
-  // near the centre carry a staircase of up to 1e-8 / |z| ulps that the exact body reproduces and a smooth table cannot.)
+  // ---- k_tab (m355_elemwise.h) ----
+  // The cdf family is tabulated in w = asinh z (the tails are linear in w), the quantiles in logit q.  The reference's
+  // own formulas lose digits next to the centre -- betainc at nu / (z^2 + nu), which rounds (studentt.py:100-105), and
+  // sqrt(1/b - 1) with b next to 1 (studentt.py:79-89) -- and the exact bodies above reproduce them as they are, which
+  // makes them staircases there: unusable as interpolation nodes.  The nodes therefore come from the same functions
+  // taken on their accurate side (tab_node / tab_ppf_node: betainc_xy with z^2 / (z^2 + nu) supplied, the complement of
+  // the root from betaincinv_), and for the cdf family the band around the centre where the reference's rounding
+  // exceeds a fifth of the parity bar -- |z| < 3e-4 sqrt(nu) / B(1/2, nu/2), 2e-4 of the mass at nu = 5 -- is a miss:
+  // those elements take the exact body, staircase included.  (Quantiles need no band: their parity is judged with the
+  // modelled rounding of the reference's sqrt(1/b - 1), tests/harness.py _student_window.)
+  // (nu <= 50: the band grows like nu -- 3 % of the mass at nu = 300 -- and the quantile's nodes get noisy with it)
+  static bool tab_ok(const K& k) { return k.nu >= 1.0 && k.nu <= 50.0 && k.sigma > 0.0 && k.sigma < kInf && k.mu - k.mu == 0.0; }
+  static M355_DEV double tab_w(double x, const K& k) {
+    const double z = fdiv_t<1, true>(x - k.mu, k.sigma), a = __builtin_fabs(z);
+    const double w = flog_tab_or_nan(a + sqrt_(__builtin_fma(a, a, 1.0)));
+    const double band = 3e-4 * sqrt_(k.nu) * exp_(-k.lbeta_h);  // (uniform: hoisted out of the loops)
+    return (a < band) ? kNaN : (z < 0.0 ? -w : w);
+  }
+  static M355_DEV double tab_x(double w, const K& k) {
+    const double e = exp_(w);
+    return __builtin_fma(k.sigma, 0.5 * (e - fdiv(1.0, e)), k.mu);
+  }
+  // cdf family at a node, smooth: I_x(nu/2, 1/2) with x = nu / (z^2 + nu) and y = z^2 / (z^2 + nu) both formed directly
+  template <int FN> static M355_DEV double tab_node(double w, const K& k) {
+    const double e = exp_(w);
+    double z = 0.5 * (e - fdiv(1.0, e));
+    if (FN == M355_LOGSF || FN == M355_SF) z = -z;
+    const double d = __builtin_fma(z, z, k.nu);
+    const double f = 0.5 * betainc_xy(0.5 * k.nu, 0.5, fdiv(k.nu, d), fdiv(z * z, d), k.lbeta_h);
+    const double l = (z < 0.0) ? flog(f) : flog1p(-f);
+    return (FN == M355_CDF || FN == M355_SF) ? exp_(l) : l;
+  }
+  // quantiles within 1e-6 of the median are misses: the reference returns exactly mu for |q - 1/2| < 1e-14 and values
+  // quantised in steps of ~1e-8 sigma next to it (b rounds to 1 - k 2^-53), which the exact body follows
+  static M355_DEV bool tab_q_miss(double q) { return __builtin_fabs(q - 0.5) < 1e-6; }
+  // quantile at a node, smooth: p = sigmoid(-|w|) is the smaller tail; b = the root of I_b(nu/2, 1/2) = 2p with its
+  // complement y, |z| = sqrt(nu y / b)
+  static M355_DEV double tab_ppf_node(double w, const K& k) {
+    const double e = exp_(-__builtin_fabs(w));
+    const double p = fdiv(e, 1.0 + e);
+    double y;
+    const double b = betaincinv_(0.5 * k.nu, 0.5, 2.0 * p, k.lbeta_h, k.ihalf_h, &y);
+    const double r = sqrt_(k.nu) * sqrt_(fdiv(y, b));
+    return __builtin_fma(w < 0.0 ? -r : r, k.sigma, k.mu);
+  }
   // studentt.py:108-119.  The nu > 1e5 arm is normal.LOGCDF(x, mu, sigma): the reference binds
   // `normal_logpdf` to normal.logcdf (studentt.py:8); reproduced as is (quirk Q1).
   static M355_DEV double logpdf(double x, const K& k) {

@@ -815,6 +815,9 @@ constexpr double kTabTailQ = 1e-9;     // the table spans the quantiles [kTabTai
 constexpr double kTabCoefTol = 1e-14;  // |c_14| + |c_15| <= kTabCoefTol * max(1, |c_0|)
 template <class T, class = void> struct has_tab_var : std::false_type {};
 template <class T> struct has_tab_var<T, std::void_t<decltype(&T::tab_w)>> : std::true_type {};
+// optional per-distribution node evaluators (smooth versions of bodies whose reference formula is a staircase somewhere)
+template <class T, class = void> struct has_tab_node : std::false_type {};
+template <class T> struct has_tab_node<T, std::void_t<decltype(&T::tab_ppf_node)>> : std::true_type {};
 template <class DD, int FN> constexpr bool tab_this() {
   return has_tab_var<DD>::value && (FN == M355_LOGCDF || FN == M355_LOGSF || FN == M355_CDF || FN == M355_SF ||
                                     FN == M355_PPF || FN == M355_ISF);
@@ -892,7 +895,11 @@ __global__ __launch_bounds__(kBlock) void k_tab(const void* __restrict__ x, int 
   for (int j = threadIdx.x; j < kTabCells * kTabN; j += kBlock) {
     const double w = wlo + h * ((double)(j >> 4) + 0.5 + 0.5 * cosv[2 * (j & 15) + 1]);
     double f;
-    if constexpr (QDOM) {
+    if constexpr (QDOM && has_tab_node<DD>::value) {
+      f = DD::tab_ppf_node(w, k);
+    } else if constexpr (has_tab_node<DD>::value) {
+      f = DD::template tab_node<FN>(w, k);
+    } else if constexpr (QDOM) {
       const double e = exp_(-__builtin_fabs(w));
       const double p = fdiv(e, 1.0 + e);  // the smaller of q, 1 - q
       if (w <= 0.0) {
@@ -935,7 +942,11 @@ __global__ __launch_bounds__(kBlock) void k_tab(const void* __restrict__ x, int 
   if (threadIdx.x < kTabCells) {
     const double* c = coef + threadIdx.x * kTabStride;
     // the parity bar is relative to max(1, |value|); a quantile must hold it relative to the root itself
-    const double scale = (QDOM || __builtin_fabs(c[0]) > 1.0) ? __builtin_fabs(c[0]) : 1.0;
+    // (sum |c_k| >= the cell's sup norm; |c_0| alone would vanish where a quantile changes sign)
+    double sum = 0.0;
+#pragma unroll
+    for (int q = 0; q < kTabN; ++q) sum += __builtin_fabs(c[q]);
+    const double scale = (QDOM || sum > 1.0) ? sum : 1.0;
     const double tail = __builtin_fabs(c[14]) + __builtin_fabs(c[15]);
     bad[threadIdx.x] = !(tail <= kTabCoefTol * scale);  // NaN / inf coefficients are bad too
   }
@@ -961,6 +972,7 @@ __global__ __launch_bounds__(kBlock) void k_tab(const void* __restrict__ x, int 
     if constexpr (QDOM) {
       const double qq = (FN == M355_ISF) ? 1.0 - xv : xv;
       wv = flog_tab_or_nan(fdiv_t<1, true>(qq, 1.0 - qq));
+      if constexpr (has_tab_node<DD>::value) wv = DD::tab_q_miss(qq) ? kNaN : wv;
     } else {
       wv = DD::tab_w(xv, k);
     }

@@ -712,11 +712,15 @@ M355_DEV double betaincinv_guess(double a, double b, double p, double lbeta) {
 // ihalf = betainc_half(a, b, lbeta) if the caller has it (NaN: evaluated here).
 // Inlined into its callers (not __noinline__ like the other heavy functions): a register budget can only be given to a
 // kernel, and the binned quantile kernels give one (Dist<>::kMinWaves, m355_elemwise.h).
-M355_DEV double betaincinv_(double a, double b, double p, double lbeta, double ihalf = kNaN) {
+// y_out (optional) receives 1 - root with the relative accuracy of whichever of the two is small (the iterate itself).
+M355_DEV double betaincinv_(double a, double b, double p, double lbeta, double ihalf = kNaN, double* y_out = nullptr) {
+  if (y_out) *y_out = kNaN;
   if (!(a > 0.0) || !(b > 0.0) || !(p >= 0.0) || !(p <= 1.0)) return kNaN;
-  if (p == 0.0) return 0.0;
-  if (p == 1.0) return 1.0;
-  if (a == b && p == 0.5) return 0.5;  // the symmetric median, exactly (skew_studentt.ppf(0.5; a = b) must be mu)
+  if (p == 0.0 || p == 1.0 || (a == b && p == 0.5)) {  // (the symmetric median exactly: skew_studentt.ppf(0.5; a = b) must be mu)
+    const double r = (p == 0.0) ? 0.0 : (p == 1.0 ? 1.0 : 0.5);
+    if (y_out) *y_out = 1.0 - r;
+    return r;
+  }
   const bool rep_y = p > ((ihalf == ihalf) ? ihalf : betainc_xy(a, b, 0.5, 0.5, lbeta));
   // Equation: I_x(a,b) = p for p <= 1/2, else I_y(b,a) = 1-p (exact), so that the small tail
   // keeps full relative accuracy; betainc_xy takes x and y separately, so either equation can
@@ -779,6 +783,7 @@ M355_DEV double betaincinv_(double a, double b, double p, double lbeta, double i
     t = tn;
     if (dt <= (safeguarded ? 4.0 * kEps : (halley ? kRootStepHalley : kRootStep)) * t) break;  // as in gammaincinv_p
   }
+  if (y_out) *y_out = rep_y ? t : 1.0 - t;
   return rep_y ? 1.0 - t : t;
 }
 

@@ -399,7 +399,10 @@ def test_binomial_logpmf_large_counts(gpu, n, p):
 @pytest.mark.parametrize("name, params", [("gamma", (2.5, 1.3)), ("gamma", (1.0, 0.2)), ("gamma", (400.0, 2.0)),
                                           ("gamma", (8e3, 1e-3)), ("beta", (2.0, 5.0)), ("beta", (1.0, 1.0)),
                                           ("beta", (60.0, 1.5)), ("beta", (150.0, 300.0)), ("gamma", (0.3, 1.0)),
-                                          ("beta", (0.5, 0.5)), ("gamma", (3e5, 1e-3)), ("beta", (300.0, 800.0))])
+                                          ("beta", (0.5, 0.5)), ("gamma", (3e5, 1e-3)), ("beta", (300.0, 800.0)),
+                                          ("studentt", (5.0, 0.0, 2.0)), ("studentt", (1.0, 1.0, 0.5)),
+                                          ("studentt", (30.0, -3.0, 1e-3)), ("studentt", (300.0, 0.0, 1.0)),
+                                          ("studentt", (0.5, 0.0, 1.0))])
 def test_tabulated_kernel(gpu, name, params):
     """k_tab (per-launch Chebyshev tables of logcdf / logsf / cdf / sf for scalar parameters, m355_elemwise.h), forced
     onto a small input through m355_set_tab_min_n: against the oracle at the parity bar and against the exact kernels at
@@ -416,12 +419,19 @@ def test_tabulated_kernel(gpu, name, params):
     if name == "gamma":
         x = rng.gamma(params[0], 1.0 / params[1], n)
         special = np.array([nan, inf, -inf, 0.0, -1.0, 5e-324, 1e-300, 1e300, x.min() * 1e-6, x.max() * 30])
+    elif name == "studentt":
+        nu, mu, sigma = params
+        x = mu + sigma * rng.standard_t(nu, n)
+        x[100:3000] = mu + sigma * rng.normal(0, 1e-3, 2900)  # the band around the centre and its edges
+        special = np.array([nan, inf, -inf, mu, mu + 1e-9 * sigma, mu - 1e-7 * sigma, mu + 1e30 * sigma, mu - 1e30 * sigma])
     else:
         x = rng.beta(params[0], params[1], n)
         special = np.array([nan, inf, -inf, 0.0, 1.0, -0.5, 1.5, 5e-324, 1e-300, 1 - 2.0**-20, x.min() * 1e-6])
     x[: special.size] = special
     if name == "gamma":
         tabulated = 1.0 <= params[0] <= 1e4
+    elif name == "studentt":
+        tabulated = 1.0 <= params[0] <= 50.0
     else:
         tabulated = min(params) >= 1.0 and sum(params) <= 500.0
     for fn in ("logcdf", "logsf", "cdf", "sf"):
@@ -450,7 +460,7 @@ def test_tabulated_kernel(gpu, name, params):
     q = rng.uniform(0, 1, n)
     q[:2000] = np.exp(rng.uniform(-20, 0, 2000))        # lower tail inside the table
     q[2000:4000] = 1 - np.exp(rng.uniform(-20, 0, 2000))  # upper tail inside the table (1 - q exact)
-    specq = np.array([nan, 0.0, 1.0, -0.1, 1.1, 1e-300, 1e-12, 1 - 2.0**-53, 1 - 1e-12])
+    specq = np.array([nan, 0.0, 1.0, -0.1, 1.1, 1e-300, 1e-12, 1 - 2.0**-53, 1 - 1e-12, 0.5, 0.5 + 1e-15])
     q[4000 : 4000 + specq.size] = specq
     for fn in ("ppf", "isf"):
         old = L.m355_set_tab_min_n(2**62)
@@ -460,11 +470,14 @@ def test_tabulated_kernel(gpu, name, params):
             tab = getattr(m, fn)(q, *params)
         finally:
             L.m355_set_tab_min_n(old)
-        sp_ = slice(4000, 4000 + specq.size)
+        sp_ = slice(4000, 4000 + (specq.size if name == "studentt" else 9))  # (the median is a miss for studentt only)
         assert np.array_equal(tab[sp_], exact[sp_], equal_nan=True), (fn, specq, tab[sp_], exact[sp_])
         assert np.array_equal(np.isnan(tab), np.isnan(exact))
         fin = np.isfinite(exact)
-        assert np.all(np.abs(tab[fin] - exact[fin]) <= 2e-13 * np.abs(exact[fin])), fn
+        if name == "studentt":  # next to the median the exact body follows the reference's quantised sqrt(1/b - 1)
+            assert np.all(H.ppf_close(name, fn, params, tab[fin], exact[fin])), fn
+        else:
+            assert np.all(np.abs(tab[fin] - exact[fin]) <= 2e-13 * np.abs(exact[fin])), fn
         if tabulated:
             with np.errstate(all="ignore"):
                 exp = R.TABLE[f"{name}_{fn}"](q, *params)
