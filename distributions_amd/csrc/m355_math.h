@@ -245,6 +245,11 @@ M355_HD double flog_tab(double x) {
   res = res + log_c;
   return __builtin_fma(ef, sconst(kLn2Hi), res);
 }
+// 2^-e with 2^e ~ m (m > 0 finite and normal; 1 otherwise): an exact scale for k_tab's log variables
+M355_HD double pow2_near_inv(double m) {
+  const int e = (m > 0x1p-900 && m < 0x1p900) ? hw_frexp_exp(m) : 0;
+  return __builtin_bit_cast(double, (unsigned long long)(1023 - e) << 52);
+}
 // flog_tab without its branch: NaN for every argument flog_tab hands to flog (x <= 0, subnormal, inf, NaN).  For
 // callers that treat those as misses anyway (k_tab's table variable).
 M355_HD double flog_tab_or_nan(double x) {
