@@ -518,12 +518,20 @@ template <> struct Dist<M355_POISSON> {
   static M355_DEV double logpdf(double x, const K& k) {
     return (xlogy0_l(x, k.logmu) - lgamma1p_obs(x)) - k.mu;
   }
+  // k_dtab (m355_elemwise.h): window of integers for the cdf family
+  static bool dtab_range(const K& k, double& lo, int& len) { return dtab_window(k.mu, sqrt(k.mu), 0.0, kInf, lo, len); }
   static M355_DEV double cdf(double x, const K& k) {  // poisson.py:49-50
     return cdf_bounds(gammainc_q(x + 1.0, k.mu, lgamma_(x + 1.0)), x, 0.0, kInf);
   }
   static M355_DEV double sf(double x, const K& k) {  // poisson.py:58-59
     const double a = floor_(x) + 1.0;
     return sf_bounds(gammainc_p(a, k.mu, lgamma_(a)), x, 0.0, kInf);
+  }
+  // the pieces of the quantile search, named so that k_dtab can run the same search on tabulated values
+  static M355_DEV double dtab_cdf(double v, const K& k) { return cdf(v, k); }
+  static M355_DEV double dtab_pmf(double v, const K& k) { return exp_(logpdf(v, k)); }
+  template <class C, class P> static M355_DEV double ppf_with(double q, const K& k, C c, P p) {
+    return find_ppf_discrete(q, k.mu, 0.0, kInf, c, p);
   }
   template <int FN> static M355_DEV double eval(double x, const K& k) {
     if constexpr (FN == M355_LOGPDF) return logpdf(x, k);
@@ -534,8 +542,7 @@ template <> struct Dist<M355_POISSON> {
     if constexpr (FN == M355_LOGSF) return flog(sf(x, k));    // poisson.py:78-79
     if constexpr (FN == M355_PPF || FN == M355_ISF) {         // poisson.py:53-55, 62-63
       const double q = (FN == M355_ISF) ? 1.0 - x : x;
-      return find_ppf_discrete(q, k.mu, 0.0, kInf, [&](double v) { return cdf(v, k); },
-                               [&](double v) { return exp_(logpdf(v, k)); });
+      return ppf_with(q, k, [&](double v) { return dtab_cdf(v, k); }, [&](double v) { return dtab_pmf(v, k); });
     }
     return kNaN;
   }
@@ -571,9 +578,18 @@ template <> struct Dist<M355_BINOMIAL> {
     return ((x < 0.0) | (x > k.n)) ? -kInf : r;
   }
   static M355_DEV double logpdf(double x, const K& k) { return logpdf_t<false>(x, k); }
+  static bool dtab_range(const K& k, double& lo, int& len) {
+    return dtab_window(k.n * k.p, sqrt(k.n * k.p * (1.0 - k.p)), 0.0, k.n, lo, len);
+  }
   static M355_DEV double cdf(double x, const K& k) {  // binomial.py:45-46
     const double a = k.n - x, b = x + 1.0;
     return cdf_bounds(betainc_(a, b, 1.0 - k.p, lbeta_(a, b)), x, 0.0, k.n);
+  }
+  // the pieces of the quantile search, named so that k_dtab can run the same search on tabulated values
+  static M355_DEV double dtab_cdf(double v, const K& k) { return cdf(v, k); }
+  static M355_DEV double dtab_pmf(double v, const K& k) { return exp_(logpdf(v, k)); }
+  template <class C, class P> static M355_DEV double ppf_with(double q, const K& k, C c, P p) {
+    return find_ppf_discrete(q, k.n * k.p, 0.0, k.n, c, p);
   }
   template <int FN> static M355_DEV double eval(double x, const K& k) {
     if constexpr (FN == M355_LOGPDF) return logpdf_t<true>(x, k);
@@ -584,8 +600,7 @@ template <> struct Dist<M355_BINOMIAL> {
     if constexpr (FN == M355_LOGSF) return flog1p(-cdf(x, k));  // binomial.py:82-83
     if constexpr (FN == M355_PPF || FN == M355_ISF) {           // binomial.py:49-51, 58-59 (x0 = mean = n p)
       const double q = (FN == M355_ISF) ? 1.0 - x : x;
-      return find_ppf_discrete(q, k.n * k.p, 0.0, k.n, [&](double v) { return cdf(v, k); },
-                               [&](double v) { return exp_(logpdf(v, k)); });
+      return ppf_with(q, k, [&](double v) { return dtab_cdf(v, k); }, [&](double v) { return dtab_pmf(v, k); });
     }
     return kNaN;
   }

@@ -136,7 +136,16 @@ template <> struct Dist<M355_NEGATIVEBINOMIAL> {
   static constexpr int kBinned = 1;
   static constexpr int NP = 2;
   using K = NegBinK;
+  static bool dtab_range(const K& k, double& lo, int& len) {
+    return dtab_window(k.n * (1.0 - k.p) / k.p, sqrt(k.n * (1.0 - k.p)) / k.p, 0.0, kInf, lo, len);
+  }
   static M355_HD K derive(const double* p) { return negbin_derive(p[0], p[1]); }
+  // the pieces of the quantile search, named so that k_dtab can run the same search on tabulated values
+  static M355_DEV double dtab_cdf(double v, const K& k) { return negbin_cdf(v, k); }
+  static M355_DEV double dtab_pmf(double v, const K& k) { return exp_(negbin_logpdf(v, k)); }
+  template <class C, class P> static M355_DEV double ppf_with(double q, const K& k, C c, P p) {
+    return find_ppf_discrete(q, k.n * (1.0 - k.p) / k.p, 0.0, kInf, c, p);
+  }
   template <int FN> static M355_DEV double eval(double x, const K& k) {
     if constexpr (FN == M355_LOGPDF) return negbin_logpdf(x, k);
     if constexpr (FN == M355_PDF) return exp_(negbin_logpdf(x, k));
@@ -146,8 +155,7 @@ template <> struct Dist<M355_NEGATIVEBINOMIAL> {
     if constexpr (FN == M355_LOGSF) return flog(negbin_sf(x, k));
     if constexpr (FN == M355_PPF || FN == M355_ISF) {
       const double q = (FN == M355_ISF) ? 1.0 - x : x;
-      return find_ppf_discrete(q, k.n * (1.0 - k.p) / k.p, 0.0, kInf, [&](double v) { return negbin_cdf(v, k); },
-                               [&](double v) { return exp_(negbin_logpdf(v, k)); });
+      return ppf_with(q, k, [&](double v) { return dtab_cdf(v, k); }, [&](double v) { return dtab_pmf(v, k); });
     }
     return kNaN;
   }
@@ -158,6 +166,11 @@ template <> struct Dist<M355_BETABINOMIAL> {
   static constexpr int kBinned = 1;
   static constexpr int NP = 3;
   struct K { double n, a, b, c; };  // c: the x-independent gammaln terms
+  static bool dtab_range(const K& k, double& lo, int& len) {  // the whole support when it fits, else around the mean
+    const double m = k.n * k.a / (k.a + k.b);
+    const double v = m * k.b / (k.a + k.b) * (k.a + k.b + k.n) / (k.a + k.b + 1.0);
+    return dtab_window(m, k.n < (double)kDTabMax ? k.n : sqrt(v), 0.0, k.n, lo, len);
+  }
   static M355_HD K derive(const double* p) {
     const double n = p[0], a = p[1], b = p[2];
     return K{n, a, b, (((lgamma_(n + 1.0) - lgamma_(n + a + b)) + lgamma_(a + b)) - lgamma_(a)) - lgamma_(b)};
@@ -175,6 +188,12 @@ template <> struct Dist<M355_BETABINOMIAL> {
     for (double j = 0.0; j <= top; j += 1.0) s += exp_(logpdf(j, k));
     return s;
   }
+  // the pieces of the quantile search, named so that k_dtab can run the same search on tabulated values
+  static M355_DEV double dtab_cdf(double v, const K& k) { return cdf(v, k); }
+  static M355_DEV double dtab_pmf(double v, const K& k) { return exp_(logpdf(v, k)); }
+  template <class C, class P> static M355_DEV double ppf_with(double q, const K& k, C c, P p) {
+    return find_ppf_discrete(q, k.n * k.a / (k.a + k.b), 0.0, k.n, c, p);
+  }
   template <int FN> static M355_DEV double eval(double x, const K& k) {
     if constexpr (FN == M355_LOGPDF) return logpdf(x, k);
     if constexpr (FN == M355_PDF) return exp_(logpdf(x, k));
@@ -184,8 +203,7 @@ template <> struct Dist<M355_BETABINOMIAL> {
     if constexpr (FN == M355_LOGSF) return flog(1.0 - cdf(x, k));
     if constexpr (FN == M355_PPF || FN == M355_ISF) {
       const double q = (FN == M355_ISF) ? 1.0 - x : x;
-      return find_ppf_discrete(q, k.n * k.a / (k.a + k.b), 0.0, k.n, [&](double v) { return cdf(v, k); },
-                               [&](double v) { return exp_(logpdf(v, k)); });
+      return ppf_with(q, k, [&](double v) { return dtab_cdf(v, k); }, [&](double v) { return dtab_pmf(v, k); });
     }
     return kNaN;
   }
@@ -196,6 +214,10 @@ template <> struct Dist<M355_HYPERGEOMETRIC> {
   static constexpr int kBinned = 1;
   static constexpr int NP = 3;
   struct K { double N, k, n, lo, hi, lbNn, lgk1, lgNk1; };
+  static bool dtab_range(const K& k, double& lo, int& len) {
+    const double m = k.n * k.k / k.N;
+    return dtab_window(m, sqrt(m * (1.0 - k.k / k.N)), k.lo, k.hi, lo, len);
+  }
   static M355_DEV double logbinom(double n, double k) { return (lgamma_(n + 1.0) - lgamma_(k + 1.0)) - lgamma_(n - k + 1.0); }
   static M355_HD K derive(const double* p) {
     const double N = p[0], k = p[1], n = p[2];
@@ -220,6 +242,12 @@ template <> struct Dist<M355_HYPERGEOMETRIC> {
     for (double j = 0.0; j <= top; j += 1.0) s += exp_(logpdf(j, k));
     return s;
   }
+  // the pieces of the quantile search, named so that k_dtab can run the same search on tabulated values
+  static M355_DEV double dtab_cdf(double v, const K& k) { return cdf(v, k); }
+  static M355_DEV double dtab_pmf(double v, const K& k) { return exp_(logpdf(v, k)); }
+  template <class C, class P> static M355_DEV double ppf_with(double q, const K& k, C c, P p) {
+    return find_ppf_discrete(q, k.n * k.k / k.N, k.lo, k.hi, c, p);
+  }
   template <int FN> static M355_DEV double eval(double x, const K& k) {
     if constexpr (FN == M355_LOGPDF) return logpdf(x, k);
     if constexpr (FN == M355_PDF) return exp_(logpdf(x, k));
@@ -229,8 +257,7 @@ template <> struct Dist<M355_HYPERGEOMETRIC> {
     if constexpr (FN == M355_LOGSF) return flog1p(-cdf(x, k));
     if constexpr (FN == M355_PPF || FN == M355_ISF) {
       const double q = (FN == M355_ISF) ? 1.0 - x : x;
-      return find_ppf_discrete(q, k.n * k.k / k.N, k.lo, k.hi, [&](double v) { return cdf(v, k); },
-                               [&](double v) { return exp_(logpdf(v, k)); });
+      return ppf_with(q, k, [&](double v) { return dtab_cdf(v, k); }, [&](double v) { return dtab_pmf(v, k); });
     }
     return kNaN;
   }
@@ -243,6 +270,9 @@ template <> struct Dist<M355_ZI_POISSON> {
   static constexpr int kBinned = 1;
   static constexpr int NP = 2;
   struct K { double psi, logpsi, log_zero; Dist<M355_POISSON>::K b; };
+  static bool dtab_range(const K& k, double& lo, int& len) {  // the base distribution's window, down to 0
+    return dtab_window(0.5 * k.b.mu, 0.5 * k.b.mu / 9.0 + sqrt(k.b.mu), 0.0, kInf, lo, len);
+  }
   static M355_HD K derive(const double* p) {
     return K{p[0], flog(p[0]), flog((1.0 - p[0]) + p[0] * ::exp(-p[1])), Dist<M355_POISSON>::derive(p + 1)};
   }
@@ -256,6 +286,12 @@ template <> struct Dist<M355_ZI_POISSON> {
     return cdf_bounds((1.0 - k.psi) + k.psi * Dist<M355_POISSON>::cdf(x, k.b), x, 0.0, kInf);
   }
   static M355_DEV double sf(double x, const K& k) { return sf_bounds(k.psi * Dist<M355_POISSON>::sf(x, k.b), x, 0.0, kInf); }
+  // the pieces of the quantile search, named so that k_dtab can run the same search on tabulated values
+  static M355_DEV double dtab_cdf(double v, const K& k) { return cdf(v, k); }
+  static M355_DEV double dtab_pmf(double v, const K& k) { return pdf(v, k); }
+  template <class C, class P> static M355_DEV double ppf_with(double q, const K& k, C c, P p) {
+    return find_ppf_discrete(q, k.b.mu, 0.0, kInf, c, p);
+  }
   template <int FN> static M355_DEV double eval(double x, const K& k) {
     if constexpr (FN == M355_LOGPDF) return logpdf(x, k);
     if constexpr (FN == M355_PDF) return pdf(x, k);
@@ -269,7 +305,7 @@ template <> struct Dist<M355_ZI_POISSON> {
     if constexpr (FN == M355_LOGSF) return flog(sf(x, k));
     if constexpr (FN == M355_PPF || FN == M355_ISF) {
       const double q = (FN == M355_ISF) ? 1.0 - x : x;
-      return find_ppf_discrete(q, k.b.mu, 0.0, kInf, [&](double v) { return cdf(v, k); }, [&](double v) { return pdf(v, k); });
+      return ppf_with(q, k, [&](double v) { return dtab_cdf(v, k); }, [&](double v) { return dtab_pmf(v, k); });
     }
     return kNaN;
   }
@@ -279,6 +315,10 @@ template <> struct Dist<M355_ZI_BINOMIAL> {
   static constexpr int kBinned = 1;
   static constexpr int NP = 3;
   struct K { double psi, logpsi, log_zero; Dist<M355_BINOMIAL>::K b; };
+  static bool dtab_range(const K& k, double& lo, int& len) {
+    const double m = k.b.n * k.b.p;
+    return dtab_window(0.5 * m, 0.5 * m / 9.0 + sqrt(m * (1.0 - k.b.p)), 0.0, k.b.n, lo, len);
+  }
   static M355_HD K derive(const double* p) {
     return K{p[0], flog(p[0]), flog((1.0 - p[0]) + p[0] * ::pow(1.0 - p[2], p[1])), Dist<M355_BINOMIAL>::derive(p + 1)};
   }
@@ -288,6 +328,12 @@ template <> struct Dist<M355_ZI_BINOMIAL> {
   }
   static M355_DEV double cdf(double x, const K& k) {
     return cdf_bounds((1.0 - k.psi) + k.psi * Dist<M355_BINOMIAL>::cdf(x, k.b), x, 0.0, k.b.n);
+  }
+  // the pieces of the quantile search, named so that k_dtab can run the same search on tabulated values
+  static M355_DEV double dtab_cdf(double v, const K& k) { return cdf(v, k); }
+  static M355_DEV double dtab_pmf(double v, const K& k) { return exp_(logpdf(v, k)); }
+  template <class C, class P> static M355_DEV double ppf_with(double q, const K& k, C c, P p) {
+    return find_ppf_discrete(q, k.psi * k.b.n * k.b.p, 0.0, k.b.n, c, p);
   }
   template <int FN> static M355_DEV double eval(double x, const K& k) {
     if constexpr (FN == M355_LOGPDF) return logpdf(x, k);
@@ -302,8 +348,7 @@ template <> struct Dist<M355_ZI_BINOMIAL> {
     if constexpr (FN == M355_LOGSF) return flog1p(-cdf(x, k));
     if constexpr (FN == M355_PPF || FN == M355_ISF) {
       const double q = (FN == M355_ISF) ? 1.0 - x : x;
-      return find_ppf_discrete(q, k.psi * k.b.n * k.b.p, 0.0, k.b.n, [&](double v) { return cdf(v, k); },
-                               [&](double v) { return exp_(logpdf(v, k)); });
+      return ppf_with(q, k, [&](double v) { return dtab_cdf(v, k); }, [&](double v) { return dtab_pmf(v, k); });
     }
     return kNaN;
   }
@@ -313,6 +358,10 @@ template <> struct Dist<M355_ZI_NEGATIVEBINOMIAL> {
   static constexpr int kBinned = 1;
   static constexpr int NP = 3;
   struct K { double psi, logpsi, log_zero; NegBinK b; };
+  static bool dtab_range(const K& k, double& lo, int& len) {
+    const double m = k.b.n * (1.0 - k.b.p) / k.b.p;
+    return dtab_window(0.5 * m, 0.5 * m / 9.0 + sqrt(k.b.n * (1.0 - k.b.p)) / k.b.p, 0.0, kInf, lo, len);
+  }
   static M355_HD K derive(const double* p) {
     return K{p[0], flog(p[0]), flog((1.0 - p[0]) + p[0] * ::pow(p[2], p[1])), negbin_derive(p[1], p[2])};
   }
@@ -326,6 +375,12 @@ template <> struct Dist<M355_ZI_NEGATIVEBINOMIAL> {
     return cdf_bounds((1.0 - k.psi) + k.psi * negbin_cdf(x, k.b), x, 0.0, kInf);
   }
   static M355_DEV double sf(double x, const K& k) { return sf_bounds(k.psi * negbin_sf(x, k.b), x, 0.0, kInf); }
+  // the pieces of the quantile search, named so that k_dtab can run the same search on tabulated values
+  static M355_DEV double dtab_cdf(double v, const K& k) { return cdf(v, k); }
+  static M355_DEV double dtab_pmf(double v, const K& k) { return pdf(v, k); }
+  template <class C, class P> static M355_DEV double ppf_with(double q, const K& k, C c, P p) {
+    return find_ppf_discrete(q, k.psi * k.b.n * (1.0 - k.b.p) / k.b.p, 0.0, kInf, c, p);
+  }
   template <int FN> static M355_DEV double eval(double x, const K& k) {
     if constexpr (FN == M355_LOGPDF) return logpdf(x, k);
     if constexpr (FN == M355_PDF) return pdf(x, k);
@@ -339,8 +394,7 @@ template <> struct Dist<M355_ZI_NEGATIVEBINOMIAL> {
     if constexpr (FN == M355_LOGSF) return flog(sf(x, k));
     if constexpr (FN == M355_PPF || FN == M355_ISF) {
       const double q = (FN == M355_ISF) ? 1.0 - x : x;
-      return find_ppf_discrete(q, k.psi * k.b.n * (1.0 - k.b.p) / k.b.p, 0.0, kInf, [&](double v) { return cdf(v, k); },
-                               [&](double v) { return pdf(v, k); });
+      return ppf_with(q, k, [&](double v) { return dtab_cdf(v, k); }, [&](double v) { return dtab_pmf(v, k); });
     }
     return kNaN;
   }

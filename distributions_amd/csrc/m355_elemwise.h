@@ -1023,6 +1023,106 @@ __global__ __launch_bounds__(kBlock) void k_tab(const void* __restrict__ x, int 
   }
 }
 
+// ---- Discrete families, scalar parameters, large n: the function of an integer, looked up ------------------------------
+// cdf / sf / logcdf / logsf of a count are functions of an integer that lives, for all practical data, in a window of a
+// few hundred to two thousand values around the mean; the exact bodies cost 500-5000 operations each (gammainc,
+// betainc, sums of pmf terms).  k_dtab has every workgroup evaluate the exact body once per integer of the window
+// [lo, lo + len) that Dist<>::dtab_range proposes (host side, from mean and standard deviation: generous, clipped to the
+// support, at most kDTabMax values) and then answers integer-valued arguments inside the window from LDS; everything
+// else -- outside the window, non-integers, NaN -- takes the exact body.  The looked-up value IS the exact body's value
+// for that argument: results are bit-identical to the other kernels'.
+template <class T, class = void> struct has_dtab : std::false_type {};
+template <class T> struct has_dtab<T, std::void_t<decltype(&T::dtab_range)>> : std::true_type {};
+template <class DD, int FN> constexpr bool dtab_this() {
+  return has_dtab<DD>::value && (FN == M355_LOGCDF || FN == M355_LOGSF || FN == M355_CDF || FN == M355_SF);
+}
+template <int D, int FN>
+__global__ __launch_bounds__(kBlock) void k_dtab(const void* __restrict__ x, int xdt, void* __restrict__ out, int odt,
+                                                 long long n, const typename Dist<D>::K k, double lo, int len) {
+  using DD = Dist<D>;
+  __shared__ double tab[kDTabMax];
+  if constexpr (uses_log_table<DD>::value) log_table_init();
+  for (int j = threadIdx.x; j < len; j += kBlock) tab[j] = DD::template eval<FN>(lo + (double)j, k);
+  __syncthreads();
+  const double flen = (double)len;
+  auto lookup = [&](double xv, bool& miss) -> double {
+    const double j = xv - lo;
+    const bool hit = (j >= 0.0) & (j < flen) & (__builtin_floor(xv) == xv);
+    miss |= !hit;
+    return tab[hit ? (int)j : 0];
+  };
+  const long long ntiles = n / kTile;
+  for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const long long base = tile * kTile + threadIdx.x * kVec;
+    double v[kUnroll][kVec], r[kUnroll][kVec];
+    bool ms[kUnroll][kVec];
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) load2<0>(x, xdt, base + u * (kBlock * kVec), v[u][0], v[u][1]);
+    bool miss = false;
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) {
+#pragma unroll
+      for (int q = 0; q < kVec; ++q) {
+        ms[u][q] = false;
+        r[u][q] = lookup(v[u][q], ms[u][q]);
+        miss |= ms[u][q];
+      }
+    }
+    if (miss) {
+#pragma unroll 1
+      for (int e = 0; e < kUnroll * kVec; ++e) {
+        if (ms[e / kVec][e % kVec]) r[e / kVec][e % kVec] = tab_exact<D, FN>(v[e / kVec][e % kVec], k);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) store2<0>(out, odt, base + u * (kBlock * kVec), r[u][0], r[u][1]);
+  }
+  for (long long i = ntiles * kTile + (long long)blockIdx.x * kBlock + threadIdx.x; i < n; i += (long long)gridDim.x * kBlock) {
+    const double xv = load1(x, xdt, i);
+    bool m = false;
+    double rv = lookup(xv, m);
+    if (m) rv = tab_exact<D, FN>(xv, k);
+    store1(out, odt, i, rv);
+  }
+}
+
+// Quantiles of the same families: find_ppf_discrete (optimization.py:102-129) itself, step for step, with the cdf and
+// pmf values it asks for taken from two tables over the window (exact bodies outside it).  The values are the exact
+// bodies' values, the iteration is the same code (Dist<>::ppf_with), so every result -- the cycles and the iterates the
+// loop stops at after 100 rounds included -- is bit-identical to the other kernels'; a step costs three LDS reads
+// instead of two incomplete gamma / beta functions and a pmf.
+template <int D> __device__ __noinline__ double dtab_cdf_exact(double v, const typename Dist<D>::K& k) { return Dist<D>::dtab_cdf(v, k); }
+template <int D> __device__ __noinline__ double dtab_pmf_exact(double v, const typename Dist<D>::K& k) { return Dist<D>::dtab_pmf(v, k); }
+
+template <int D, int FN>
+__global__ __launch_bounds__(kBlock) void k_dtab_ppf(const void* __restrict__ x, int xdt, void* __restrict__ out, int odt,
+                                                     long long n, const typename Dist<D>::K k, double lo, int len) {
+  using DD = Dist<D>;
+  __shared__ double tc[kDTabMax], tp[kDTabMax];
+  if constexpr (uses_log_table<DD>::value) log_table_init();
+  for (int j = threadIdx.x; j < len; j += kBlock) {
+    tc[j] = DD::dtab_cdf(lo + (double)j, k);
+    tp[j] = DD::dtab_pmf(lo + (double)j, k);
+  }
+  __syncthreads();
+  const double flen = (double)len;
+  auto cdf = [&](double v) -> double {
+    const double j = v - lo;
+    if ((j >= 0.0) & (j < flen) & (__builtin_floor(v) == v)) return tc[(int)j];
+    return dtab_cdf_exact<D>(v, k);
+  };
+  auto pmf = [&](double v) -> double {
+    const double j = v - lo;
+    if ((j >= 0.0) & (j < flen) & (__builtin_floor(v) == v)) return tp[(int)j];
+    return dtab_pmf_exact<D>(v, k);
+  };
+  for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < n; i += (long long)gridDim.x * kBlock) {
+    const double xv = load1(x, xdt, i);
+    const double q = (FN == M355_ISF) ? 1.0 - xv : xv;
+    store1(out, odt, i, DD::ppf_with(q, k, cdf, pmf));
+  }
+}
+
 struct GenericOps {
   DevOperand x;
   DevOperand p[kMaxParams];
@@ -1158,6 +1258,28 @@ template <int D, int FN, bool REDUCE> int launch_fn(const LaunchArgs& a) {
             hipLaunchKernelGGL((k_tab<D, FN, false>), dim3(bb), dim3(kBlock), 0, a.stream, a.x.ptr, a.x.dtype, a.out,
                                a.out_dtype, n, k);
           }
+          return (int)hipGetLastError();
+        }
+      }
+      if constexpr (!REDUCE && has_dtab<DD>::value && (FN == M355_PPF || FN == M355_ISF)) {
+        double lo = 0.0;
+        int len = 0;
+        if (n >= tab_min_n() && !binning_disabled() && DD::dtab_range(k, lo, len)) {
+          const long long want = (n + kBlock - 1) / kBlock;
+          const int bb = (int)(want > 5 * 256 ? 5 * 256 : want);  // 32 KiB of tables: five workgroups per CU
+          hipLaunchKernelGGL((k_dtab_ppf<D, FN>), dim3(bb), dim3(kBlock), 0, a.stream, a.x.ptr, a.x.dtype, a.out, a.out_dtype,
+                             n, k, lo, len);
+          return (int)hipGetLastError();
+        }
+      }
+      if constexpr (!REDUCE && dtab_this<DD, FN>()) {
+        double lo = 0.0;
+        int len = 0;
+        if (n >= tab_min_n() && !binning_disabled() && DD::dtab_range(k, lo, len)) {
+          const long long want = tiles < 1 ? 1 : tiles;
+          const int bb = (int)(want > 2 * kTabBlocks ? 2 * kTabBlocks : want);
+          hipLaunchKernelGGL((k_dtab<D, FN>), dim3(bb), dim3(kBlock), 0, a.stream, a.x.ptr, a.x.dtype, a.out, a.out_dtype, n, k,
+                             lo, len);
           return (int)hipGetLastError();
         }
       }

@@ -245,6 +245,20 @@ M355_HD double flog_tab(double x) {
   res = res + log_c;
   return __builtin_fma(ef, sconst(kLn2Hi), res);
 }
+// k_dtab (m355_elemwise.h): the integer window a discrete family proposes for its lookup table
+constexpr int kDTabMax = 2048;
+// window around (mean, sd) clipped to [slo, shi]; false if it does not fit
+inline bool dtab_window(double mean, double sd, double slo, double shi, double& lo, int& len) {
+  if (!(mean - mean == 0.0) || !(sd - sd == 0.0)) return false;
+  double a = floor(mean - 9.0 * sd - 12.0), b = ceil(mean + 14.0 * sd + 40.0);
+  a = a < slo ? slo : a;
+  b = b > shi ? shi : b;
+  if (!(b >= a) || b - a + 1.0 > (double)kDTabMax) return false;
+  lo = a;
+  len = (int)(b - a + 1.0);
+  return true;
+}
+
 // 2^-e with 2^e ~ m (m > 0 finite and normal; 1 otherwise): an exact scale for k_tab's log variables
 M355_HD double pow2_near_inv(double m) {
   const int e = (m > 0x1p-900 && m < 0x1p900) ? hw_frexp_exp(m) : 0;

@@ -489,6 +489,51 @@ def test_tabulated_kernel(gpu, name, params):
     assert L.m355_set_tab_min_n(-1) == old and L.m355_set_tab_min_n(old) == 2**21
 
 
+@pytest.mark.parametrize("name, params", [("poisson", (100.0,)), ("poisson", (0.7,)), ("binomial", (1000.0, 0.3)),
+                                          ("binomial", (12.0, 0.9)), ("negativebinomial", (10.0, 0.1)),
+                                          ("betabinomial", (100.0, 20.0, 20.0)), ("hypergeometric", (50.0, 20.0, 10.0)),
+                                          ("zi_poisson", (0.7, 10.0)), ("zi_binomial", (0.4, 60.0, 0.2)),
+                                          ("zi_negativebinomial", (0.8, 5.0, 0.3)), ("poisson", (1e7,))])
+def test_discrete_lookup_kernel(gpu, name, params):
+    """k_dtab / k_dtab_ppf (cdf / sf / logcdf / logsf of a discrete family answered from a per-launch table of the exact
+    body over a window of integers, ppf / isf by the reference's search on the tabulated values, m355_elemwise.h), forced
+    onto a small input: bit-identical to the exact kernels for counts
+    inside and outside the window, non-integers, negatives, NaN and infinities, float64 and int64 observations; a
+    window that does not fit (poisson(1e7): 14 sd > 2048 values) leaves the exact kernels in charge."""
+    from distributions_amd import _lib
+
+    L = _lib.lib()
+    rng = np.random.default_rng(41)
+    m = mod(name)
+    n = 30_000 + 11
+    k = np.asarray(m.rvs(*params, size=n, random_state=7) if hasattr(m, "rvs") else rng.integers(0, 60, n), dtype=np.float64)
+    k[:12] = [np.nan, np.inf, -np.inf, -1.0, 0.0, 0.5, 1e18, 3.0, 2.5, k.max() * 50 + 7, -0.0, 1.0]
+    for obs in (k, np.where(np.isfinite(k), k, 0).astype(np.int64)):
+        for fn in ("cdf", "sf", "logcdf", "logsf"):
+            old = L.m355_set_tab_min_n(2**62)
+            try:
+                exact = getattr(m, fn)(obs, *params)
+                L.m355_set_tab_min_n(1)
+                tab = getattr(m, fn)(obs, *params)
+            finally:
+                L.m355_set_tab_min_n(old)
+            assert np.array_equal(tab, exact, equal_nan=True), (name, fn, obs[~((tab == exact) | (np.isnan(tab) & np.isnan(exact)))][:5])
+    # quantiles: find_ppf_discrete on the tabulated cdf / pmf -- the same iterates, bit for bit
+    q = rng.uniform(0, 1, n)
+    q[:4000] = np.exp(rng.uniform(-25, 0, 4000))
+    q[4000:8000] = 1 - np.exp(rng.uniform(-25, 0, 4000))
+    q[8000:8008] = [np.nan, 0.0, 1.0, -0.5, 1.5, 1e-300, 1 - 2.0**-53, 0.5]
+    for fn in ("ppf", "isf"):
+        old = L.m355_set_tab_min_n(2**62)
+        try:
+            exact = getattr(m, fn)(q, *params)
+            L.m355_set_tab_min_n(1)
+            tab = getattr(m, fn)(q, *params)
+        finally:
+            L.m355_set_tab_min_n(old)
+        assert np.array_equal(tab, exact, equal_nan=True), (name, fn, q[~((tab == exact) | (np.isnan(tab) & np.isnan(exact)))][:5])
+
+
 @pytest.mark.parametrize("h, z", H.POLYAGAMMA_CASES)
 def test_polyagamma(gpu, h, z):
     """polyagamma: no SciPy counterpart -- every function against the oracle (series density,
