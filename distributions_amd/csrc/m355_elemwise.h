@@ -1005,11 +1005,23 @@ __global__ __launch_bounds__(kBlock) void k_tab(const void* __restrict__ x, int 
         miss |= r[u][q] != r[u][q];
       }
     }
-    if (miss) {  // rare: one out-of-line copy of the exact body serves all four slots
+    if (miss) {
+      // rare: the exact body, one out-of-line call site for the four slots (four sites cost 66 more VGPRs around the
+      // calls and a wavefront per SIMD); the slot is picked by selects on the uniform e -- indexing v and r with it
+      // would move both arrays to scratch memory for every tile
 #pragma unroll 1
       for (int e = 0; e < kUnroll * kVec; ++e) {
-        const double rv = r[e / kVec][e % kVec];
-        if (rv != rv) r[e / kVec][e % kVec] = tab_exact<D, FN>(v[e / kVec][e % kVec], k);
+        double xv = v[0][0], rv = r[0][0];
+#pragma unroll
+        for (int j = 1; j < kUnroll * kVec; ++j) {
+          xv = (e == j) ? v[j / kVec][j % kVec] : xv;
+          rv = (e == j) ? r[j / kVec][j % kVec] : rv;
+        }
+        if (rv != rv) {
+          const double ex = tab_exact<D, FN>(xv, k);
+#pragma unroll
+          for (int j = 0; j < kUnroll * kVec; ++j) r[j / kVec][j % kVec] = (e == j) ? ex : r[j / kVec][j % kVec];
+        }
       }
     }
 #pragma unroll
@@ -1069,9 +1081,12 @@ __global__ __launch_bounds__(kBlock) void k_dtab(const void* __restrict__ x, int
       }
     }
     if (miss) {
-#pragma unroll 1
-      for (int e = 0; e < kUnroll * kVec; ++e) {
-        if (ms[e / kVec][e % kVec]) r[e / kVec][e % kVec] = tab_exact<D, FN>(v[e / kVec][e % kVec], k);
+#pragma unroll
+      for (int u = 0; u < kUnroll; ++u) {
+#pragma unroll
+        for (int q = 0; q < kVec; ++q) {
+          if (ms[u][q]) r[u][q] = tab_exact<D, FN>(v[u][q], k);
+        }
       }
     }
 #pragma unroll
