@@ -152,14 +152,20 @@ template <> struct Dist<M355_GAMMA> {
     k.tsc = __builtin_bit_cast(double, (unsigned long long)(1023 - e) << 52);
     return k;
   }
-  // k_tab (m355_elemwise.h): the cdf family is tabulated in w = log x.  Shapes below 1 are left to the exact kernels:
-  // their lower quantiles sit at x ~ 1e-9^(1/alpha) and 64 cells across that range are too wide for the bulk.
+  // k_tab (m355_elemwise.h): the cdf family is tabulated in w = log x.
   // Very large shapes neither: the exact bodies' own noise (~1e-16 alpha) then exceeds what a cell must show to be used.
-  static bool tab_ok(const K& k) { return k.alpha >= 1.0 && k.alpha <= 1e4 && k.beta > 0.0 && k.beta < kInf; }
+  static bool tab_ok(const K& k) { return k.alpha >= 0.01 && k.alpha <= 1e4 && k.beta > 0.0 && k.beta < kInf; }
+  // (quantiles: ppf ~ q^(1/alpha) at the lower end, which no polynomial in logit q follows for alpha < 1)
+  static constexpr bool kTabOkFn = true;
+  template <int FN> static bool tab_ok_fn(const K& k) { return (FN != M355_PPF && FN != M355_ISF) || k.alpha >= 1.0; }
   // (x is scaled by a power of two near beta / alpha first, so that |w| stays of the order of the spread of log x: for
-  // large alpha the function is steep in w -- d log P / dw ~ sqrt(alpha) -- and log x itself would carry |log x| ulps)
-  static M355_DEV double tab_w(double x, const K& k) { return flog_tab_or_nan(x * k.tsc); }
-  static M355_DEV double tab_x(double w, const K& k) { return fdiv(exp_(w), k.tsc); }
+  // large alpha the function is steep in w -- d log P / dw ~ sqrt(alpha) -- and log x itself would carry |log x| ulps;
+  // alpha < 1: warped, see tab_warp)
+  static M355_DEV double tab_w(double x, const K& k) {
+    const double v = flog_tab_or_nan(x * k.tsc);
+    return k.alpha < 1.0 ? tab_warp(v) : v;
+  }
+  static M355_DEV double tab_x(double w, const K& k) { return fdiv(exp_(k.alpha < 1.0 ? tab_unwarp(w) : w), k.tsc); }
   // gamma.py:77-82 with (alpha-1)*log(x) as xlogy0 (quirk Q2).
   static M355_DEV double logpdf(double x, const K& k) {
     const double t = xlogy0_l(k.am1, flog_tab(x));
@@ -250,9 +256,46 @@ template <> struct Dist<M355_BETA> {
   }
   // beta.py:102-108; xlogy0(alpha+beta-1, 1) is a*log(1) == 0 (or the xlogy0 zero).
   // k_tab: the cdf family is tabulated in w = logit x (1 - x is exact for x >= 1/2); shapes below 1 as for gamma
-  static bool tab_ok(const K& k) { return k.a >= 1.0 && k.b >= 1.0 && k.a + k.b <= 500.0; }
-  static M355_DEV double tab_w(double x, const K&) { return flog_tab_or_nan(fdiv_t<1, true>(x, 1.0 - x)); }
-  static M355_DEV double tab_x(double w, const K&) { return fdiv(1.0, 1.0 + exp_(-w)); }
+  static bool tab_ok(const K& k) { return k.a >= 0.01 && k.b >= 0.01 && k.a + k.b <= 500.0; }
+  // (quantiles as for gamma; logsf / sf with alpha < 1/2: the reference's betainc at the rounded 1 - x is a staircase
+  // below x ~ 1e-6, where such a shape puts > 0.1 % of the data -- the cells there fail validation by design, and that
+  // many misses cost more than the table saves)
+  static constexpr bool kTabOkFn = true;
+  template <int FN> static bool tab_ok_fn(const K& k) {
+    if (FN == M355_PPF || FN == M355_ISF) return k.a >= 1.0 && k.b >= 1.0;
+    if (FN == M355_LOGSF || FN == M355_SF) return k.a >= 0.5;
+    return true;
+  }
+  static M355_HD bool tab_warped(const K& k) { return (k.a < 1.0) | (k.b < 1.0); }
+  // (range ends when even ppf(1e-3) / ppf(1 - 1e-3) round to 0 / 1: the outermost doubles inside the support)
+  static M355_HD double tab_cap(bool upper) { return upper ? 1.0 - 0x1p-53 : 0x1p-1000; }
+  static M355_DEV double tab_w(double x, const K& k) {
+    const double v = flog_tab_or_nan(fdiv_t<1, true>(x, 1.0 - x));
+    return tab_warped(k) ? tab_warp(v) : v;
+  }
+  static M355_DEV double tab_x(double w, const K& k) {
+    // the smaller of x, 1 - x from exp(-|v|) (for |v| in the hundreds 1 / (1 + exp(-v)) would round to 1)
+    const double v = tab_warped(k) ? tab_unwarp(w) : w;
+    const double e = exp_(-__builtin_fabs(v));
+    const double sm = fdiv(e, 1.0 + e);
+    return v < 0.0 ? sm : 1.0 - sm;
+  }
+  // Node values.  Below 1/2 the argument x = sm is a double to full relative accuracy and the node is the exact body
+  // (where the reference's own logsf is a staircase -- betainc at the rounded 1 - x, x < 1e-10 -- the cell then fails
+  // validation and those elements keep the exact body).  Above 1/2 the node's x = 1 - sm would be rounded to the grid
+  // of doubles next to 1, which the DATA is too but a node of the smooth interpolant must not be: betainc takes x and
+  // its complement separately, so the node passes sm as the complement (for a double x the reference's 1 - x is exact
+  // there, so this is the function the reference computes).
+  static constexpr bool kTabNode = true;
+  template <int FN> static M355_DEV double tab_node(double w, const K& k) {
+    const double v = tab_warped(k) ? tab_unwarp(w) : w;
+    const double e = exp_(-__builtin_fabs(v));
+    const double sm = fdiv(e, 1.0 + e);
+    if (v < 0.0) return eval<FN>(sm, k);
+    constexpr bool UP = FN == M355_LOGSF || FN == M355_SF;
+    const double I = UP ? betainc_xy(k.b, k.a, sm, 1.0 - sm, k.lbeta) : betainc_xy(k.a, k.b, 1.0 - sm, sm, k.lbeta);
+    return (FN == M355_LOGCDF || FN == M355_LOGSF) ? flog(I) : I;
+  }
   static M355_DEV double logpdf(double x, const K& k) {
     const double t = xlogy0_l(k.am1, flog_tab(x)) + xlogy0_l(k.bm1, flog_tab(1.0 - x));
     const double r = t - (0.0 + k.lbeta);
@@ -380,6 +423,7 @@ template <> struct Dist<M355_STUDENTT> {
     return __builtin_fma(k.sigma, 0.5 * (e - fdiv(1.0, e)), k.mu);
   }
   // cdf family at a node, smooth: I_x(nu/2, 1/2) with x = nu / (z^2 + nu) and y = z^2 / (z^2 + nu) both formed directly
+  static constexpr bool kTabNode = true;
   template <int FN> static M355_DEV double tab_node(double w, const K& k) {
     const double e = exp_(w);
     double z = 0.5 * (e - fdiv(1.0, e));

@@ -817,7 +817,13 @@ template <class T, class = void> struct has_tab_var : std::false_type {};
 template <class T> struct has_tab_var<T, std::void_t<decltype(&T::tab_w)>> : std::true_type {};
 // optional per-distribution node evaluators (smooth versions of bodies whose reference formula is a staircase somewhere)
 template <class T, class = void> struct has_tab_node : std::false_type {};
-template <class T> struct has_tab_node<T, std::void_t<decltype(&T::tab_ppf_node)>> : std::true_type {};
+template <class T> struct has_tab_node<T, std::void_t<decltype(&T::tab_ppf_node)>> : std::true_type {};  // quantile nodes
+template <class T, class = void> struct has_tab_ok_fn : std::false_type {};  // per-function restrictions of tab_ok
+template <class T> struct has_tab_ok_fn<T, std::void_t<decltype(T::kTabOkFn)>> : std::true_type {};
+template <class T, class = void> struct has_tab_cap : std::false_type {};
+template <class T> struct has_tab_cap<T, std::void_t<decltype(&T::tab_cap)>> : std::true_type {};
+template <class T, class = void> struct has_tab_fnode : std::false_type {};
+template <class T> struct has_tab_fnode<T, std::void_t<decltype(T::kTabNode)>> : std::true_type {};  // tab_node<FN>
 template <class DD, int FN> constexpr bool tab_this() {
   return has_tab_var<DD>::value && (FN == M355_LOGCDF || FN == M355_LOGSF || FN == M355_CDF || FN == M355_SF ||
                                     FN == M355_PPF || FN == M355_ISF);
@@ -881,8 +887,15 @@ __global__ __launch_bounds__(kBlock) void k_tab(const void* __restrict__ x, int 
     if constexpr (QDOM) {
       rng[threadIdx.x] = threadIdx.x == 0 ? -kTabLogitMax : kTabLogitMax;
     } else {
-      const double xe = DD::template eval<M355_PPF>(threadIdx.x == 0 ? kTabTailQ : 1.0 - kTabTailQ, k);
-      rng[threadIdx.x] = DD::tab_w(xe, k);
+      // (an end whose quantile is not a usable argument -- beta with b < 1: ppf(1 - 1e-9) rounds to 1 -- moves inwards)
+      double tq = kTabTailQ, we = kNaN;
+#pragma unroll 1
+      for (int it = 0; it < 4 && !(we - we == 0.0); ++it, tq *= 100.0)
+        we = DD::tab_w(DD::template eval<M355_PPF>(threadIdx.x == 0 ? tq : 1.0 - tq, k), k);
+      if constexpr (has_tab_cap<DD>::value) {  // (still none: the outermost usable argument)
+        if (!(we - we == 0.0)) we = DD::tab_w(DD::tab_cap(threadIdx.x == 1), k);
+      }
+      rng[threadIdx.x] = we;
     }
   }
   if (threadIdx.x < 64) cosv[threadIdx.x] = kCos32[threadIdx.x];
@@ -897,7 +910,7 @@ __global__ __launch_bounds__(kBlock) void k_tab(const void* __restrict__ x, int 
     double f;
     if constexpr (QDOM && has_tab_node<DD>::value) {
       f = DD::tab_ppf_node(w, k);
-    } else if constexpr (has_tab_node<DD>::value) {
+    } else if constexpr (!QDOM && has_tab_fnode<DD>::value) {
       f = DD::template tab_node<FN>(w, k);
     } else if constexpr (QDOM) {
       const double e = exp_(-__builtin_fabs(w));
@@ -1262,7 +1275,9 @@ template <int D, int FN, bool REDUCE> int launch_fn(const LaunchArgs& a) {
       const double pp[kMaxParams] = {a.p[0].scalar, a.p[1].scalar, a.p[2].scalar, a.p[3].scalar};
       const typename DD::K k = DD::derive(pp);
       if constexpr (!REDUCE && tab_this<DD, FN>()) {
-        if (n >= tab_min_n() && DD::tab_ok(k) && !binning_disabled()) {
+        bool tab_ok = DD::tab_ok(k);
+        if constexpr (has_tab_ok_fn<DD>::value) tab_ok = tab_ok && DD::template tab_ok_fn<FN>(k);
+        if (n >= tab_min_n() && tab_ok && !binning_disabled()) {
           const long long want = tiles < 1 ? 1 : tiles;
           static const int tb = [] { const char* e = getenv("M355_TAB_BLOCKS"); return e ? atoi(e) : kTabBlocks; }();
           const int bb = (int)(want > tb ? tb : want);

@@ -57,6 +57,19 @@ M355_DEV double tan_(double x) { return std::tan(x); }
 M355_DEV double pow_l(double x, double lx, double y) { (void)lx; return std::pow(x, y); }
 #endif
 
+// k_tab's second map for shapes below 1 (m355_elemwise.h): v = log x (or logit x) then spans hundreds of units -- the
+// lower quantiles sit at 1e-9^(1/shape) -- while the function is linear out there and only its bulk needs resolution;
+// cells uniform in s = asinh v are ~0.1 wide in v around the bulk and grow like |v| in the tails.
+M355_DEV double tab_warp(double v) {
+  const double a = __builtin_fabs(v);
+  const double s = flog_tab_or_nan(a + sqrt_(__builtin_fma(a, a, 1.0)));
+  return v < 0.0 ? -s : s;
+}
+M355_DEV double tab_unwarp(double s) {
+  const double e = exp_(s);
+  return 0.5 * (e - fdiv(1.0, e));
+}
+
 // log Gamma(x + 1) for an observation x (poisson / binomial logpdf: gammaln(x + 1), gammaln(n - x + 1)).  Counts are
 // small integers or large: log(x!) from a 128-entry table for integer 0 <= x < 128 (correctly rounded values), Stirling's
 // series (DLMF 5.11.1 through z^-11: |error| < 2e-18 at z = x + 1 >= 16) with one logarithm and one reciprocal above,

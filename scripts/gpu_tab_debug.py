@@ -1,25 +1,32 @@
 import os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import numpy as np, torch
-from distributions_amd import _lib, studentt
+from distributions_amd import _lib, gamma, beta
+from oracle import restatement as R
 L = _lib.lib()
 dev = torch.device("cuda:0")
-n = 8_000_000
-q = torch.rand(n, dtype=torch.float64, device=dev)
-for params in ((5.0, 0.0, 2.0), (30.0, 0.0, 1.0), (300.0, -2.0, 1.0)):
-    L.m355_set_tab_min_n(2**62); exact = studentt.ppf(q, *params)
-    L.m355_set_tab_min_n(-1); tab = studentt.ppf(q, *params)
-    same = (tab == exact).cpu().numpy()
-    w = np.log(q.cpu().numpy() / (1 - q.cpu().numpy()))
-    cell = np.floor((w + 20.723265835946928) / (2 * 20.723265835946928 / 64)).astype(int)
-    frac = np.array([same[cell == c].mean() if (cell == c).any() else np.nan for c in range(64)])
-    print(params, "miss-like cells (identical frac > 0.5):", [c for c in range(64) if frac[c] > 0.5], " overall identical", same.mean())
-    x = (params[1] + params[2] * torch.distributions.StudentT(params[0]).sample((n,))).double().to(dev)
-    L.m355_set_tab_min_n(2**62); exact = studentt.logcdf(x, *params)
-    L.m355_set_tab_min_n(-1); tab = studentt.logcdf(x, *params)
-    same = (tab == exact).cpu().numpy()
-    z = ((x - params[1]) / params[2]).cpu().numpy()
-    ww = np.arcsinh(z)
-    edges = np.quantile(ww, np.linspace(0, 1, 41))
-    fr = [same[(ww >= edges[i]) & (ww < edges[i + 1])].mean() for i in range(40)]
-    print("  logcdf identical frac by w-quantile bin:", np.round(fr, 2))
+n = 100_000_000
+def t(f):
+    torch.cuda.synchronize(); e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    f(); e0.record()
+    for _ in range(5): f()
+    e1.record(); torch.cuda.synchronize(); return e0.elapsed_time(e1) / 5
+for a in (2.5, 0.9, 0.3, 0.05, 0.01):
+    x = torch.distributions.Gamma(torch.tensor(a, dtype=torch.float64, device=dev), torch.tensor(1.0, dtype=torch.float64, device=dev)).sample((n,)).clamp_(min=1e-300)
+    for fn in ("logcdf", "logsf"):
+        f = getattr(gamma, fn)
+        L.m355_set_tab_min_n(2**62); exact = f(x, a, 1.0); te = t(lambda: f(x, a, 1.0))
+        L.m355_set_tab_min_n(2**21); tab = f(x, a, 1.0); tt = t(lambda: f(x, a, 1.0))
+        same = (tab == exact)
+        d = ((tab - exact).abs() / exact.abs().clamp(min=1)).max()
+        print("gamma", a, fn, "identical %.4f maxdiff %.2e  exact %.3f ms tab %.3f ms" % (float(same.double().mean()), float(d), te, tt))
+for a, b in ((2.0, 5.0), (0.3, 4.0), (3.0, 0.2), (0.5, 0.5), (0.05, 0.02)):
+    x = torch.distributions.Beta(torch.tensor(a, dtype=torch.float64, device=dev), torch.tensor(b, dtype=torch.float64, device=dev)).sample((n,))
+    for fn in ("logcdf", "logsf"):
+        f = getattr(beta, fn)
+        L.m355_set_tab_min_n(2**62); exact = f(x, a, b); te = t(lambda: f(x, a, b))
+        L.m355_set_tab_min_n(2**21); tab = f(x, a, b); tt = t(lambda: f(x, a, b))
+        same = (tab == exact)
+        fin = torch.isfinite(exact)
+        d = ((tab - exact).abs() / exact.abs().clamp(min=1))[fin].max()
+        print("beta", a, b, fn, "identical %.4f maxdiff %.2e  exact %.3f ms tab %.3f ms" % (float(same.double().mean()), float(d), te, tt))

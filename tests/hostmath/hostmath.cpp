@@ -189,3 +189,67 @@ extern "C" int hm_moment(int dist, int stat, long n, const double* p, double* ou
 
 extern "C" void hm_lgamma1p_obs(long n, const double* x, double* out) { for (long i = 0; i < n; ++i) out[i] = lgamma1p_obs(x[i]); }
 extern "C" void hm_digamma(long n, const double* x, double* out) { for (long i = 0; i < n; ++i) out[i] = digamma_(x[i]); }
+
+// k_tab's table build (m355_elemwise.h) restated on the host for the non-quantile functions: the range, the node values
+// through tab_x, the 16-point DCT per cell and the validation.  out = {wlo, whi, tail/scale per cell (64)}.
+template <class T, class = void> struct hm_has_tab : std::false_type {};
+template <class T> struct hm_has_tab<T, std::void_t<decltype(&T::tab_w)>> : std::true_type {};
+template <class T, class = void> struct hm_has_node : std::false_type {};
+template <class T> struct hm_has_node<T, std::void_t<decltype(T::kTabNode)>> : std::true_type {};
+template <class T, class = void> struct hm_has_cap : std::false_type {};
+template <class T> struct hm_has_cap<T, std::void_t<decltype(&T::tab_cap)>> : std::true_type {};
+template <int D, int FN> static int tab_build(const double* p, double* out) {
+  using DD = Dist<D>;
+  if constexpr (!hm_has_tab<DD>::value) {
+    return -2;
+  } else {
+    const auto k = DD::derive(p);
+    if (!DD::tab_ok(k)) return 1;
+    double rng[2];
+    for (int e = 0; e < 2; ++e) {
+      double tq = 1e-9, we = kNaN;
+      for (int it = 0; it < 4 && !(we - we == 0.0); ++it, tq *= 100.0)
+        we = DD::tab_w(DD::template eval<M355_PPF>(e == 0 ? tq : 1.0 - tq, k), k);
+      if constexpr (hm_has_cap<DD>::value) {
+        if (!(we - we == 0.0)) we = DD::tab_w(DD::tab_cap(e == 1), k);
+      }
+      rng[e] = we;
+    }
+    out[0] = rng[0];
+    out[1] = rng[1];
+    const double wlo = rng[0], h = (rng[1] - rng[0]) / 64.0;
+    const double pi = 3.14159265358979323846;
+    for (int cell = 0; cell < 64; ++cell) {
+      double f[16], c[16];
+      for (int j = 0; j < 16; ++j) {
+        const double w = wlo + h * (cell + 0.5 + 0.5 * __builtin_cos(pi * (2 * j + 1) / 32.0));
+        if constexpr (hm_has_node<DD>::value) f[j] = DD::template tab_node<FN>(w, k);
+        else f[j] = DD::template eval<FN>(DD::tab_x(w, k), k);
+      }
+      double sum = 0.0;
+      for (int m = 0; m < 16; ++m) {
+        double acc = 0.0;
+        for (int j = 0; j < 16; ++j) acc += f[j] * __builtin_cos(pi * m * (2 * j + 1) / 32.0);
+        c[m] = acc * (m == 0 ? 1.0 / 16.0 : 2.0 / 16.0);
+        sum += __builtin_fabs(c[m]);
+      }
+      const double scale = sum > 1.0 ? sum : 1.0;
+      out[2 + cell] = (__builtin_fabs(c[14]) + __builtin_fabs(c[15])) / scale;
+    }
+    return 0;
+  }
+}
+extern "C" int hm_tab_build(int dist, int fn, const double* p, double* out) {
+  switch (dist) {
+#define HM_TAB(ID, name, np)                                                \
+  case ID:                                                                  \
+    if (fn == M355_LOGCDF) return tab_build<ID, M355_LOGCDF>(p, out);       \
+    if (fn == M355_LOGSF) return tab_build<ID, M355_LOGSF>(p, out);         \
+    if (fn == M355_CDF) return tab_build<ID, M355_CDF>(p, out);             \
+    if (fn == M355_SF) return tab_build<ID, M355_SF>(p, out);               \
+    return -1;
+    M355_DIST_LIST(HM_TAB)
+#undef HM_TAB
+  }
+  return -1;
+}

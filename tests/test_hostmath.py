@@ -595,3 +595,28 @@ def test_host_lgamma1p_obs(hostlib):
         exp = sp.gammaln(x + 1.0)
     ok = (got == exp) | (np.isnan(got) & np.isnan(exp)) | (np.abs(got - exp) <= 1e-15 * np.maximum(1.0, np.abs(exp)))
     assert np.all(ok), (x[~ok][:5], got[~ok][:5], exp[~ok][:5])
+
+
+@pytest.mark.parametrize("name,params,max_bad", [
+    ("gamma", (2.5, 1.0), 0), ("gamma", (0.9, 1.0), 0), ("gamma", (0.3, 1.0), 0), ("gamma", (0.05, 2.0), 0),
+    ("gamma", (0.01, 1.0), 0), ("gamma", (0.5, 1e8), 0), ("gamma", (3000.0, 0.01), 0),
+    ("beta", (2.0, 3.0), 0), ("beta", (0.3, 4.0), 0), ("beta", (3.0, 0.2), 0), ("beta", (0.5, 0.5), 0),
+    ("beta", (0.02, 0.05), 0), ("beta", (50.0, 0.5), 0), ("beta", (200.0, 1.5), 0),
+    ("studentt", (3.0, 0.5, 2.0), 2), ("chisquared", (7.0,), 0), ("inversegamma", (3.0, 2.0), 0),
+])
+def test_host_tab_build(hostlib, name, params, max_bad):
+    """k_tab's table build (m355_elemwise.h) restated on the host (hm_tab_build): with the range ends, the warped
+    variable for shapes below 1 and the complement-aware nodes of beta, every cell of the logcdf / cdf table validates
+    (|c14| + |c15| <= 1e-14 of its scale); the range is finite and increasing.  (logsf / sf of beta with alpha < 1 keep
+    poisoned cells where the reference itself is a staircase -- betainc at the rounded 1 - x -- and those elements take
+    the exact body: checked on the GPU, tests/test_gpu_elemwise.py::test_tabulated_kernel.)"""
+    pp = np.array(list(params) + [0.0] * (4 - len(params)), dtype=np.float64)
+    for fn in ("logcdf", "cdf"):
+        out = np.zeros(66)
+        rc = hostlib.hm_tab_build(DIST[name], FN[fn], _ptr(pp), _ptr(out))
+        assert rc == 0
+        assert np.isfinite(out[0]) and np.isfinite(out[1]) and out[1] > out[0]
+        assert int(np.sum(~(out[2:] <= 1e-14))) <= max_bad, (fn, np.where(~(out[2:] <= 1e-14))[0])
+    out = np.zeros(66)
+    assert hostlib.hm_tab_build(DIST[name], FN["logsf"], _ptr(pp), _ptr(out)) == 0
+    assert int(np.sum(~(out[2:] <= 1e-14))) <= (16 if name == "beta" else max_bad)
