@@ -154,16 +154,16 @@ template <> struct Dist<M355_GAMMA> {
   }
   // k_tab (m355_elemwise.h): the cdf family is tabulated in w = log x.
   // Very large shapes neither: the exact bodies' own noise (~1e-16 alpha) then exceeds what a cell must show to be used.
-  static bool tab_ok(const K& k) { return k.alpha >= 0.01 && k.alpha <= 1e4 && k.beta > 0.0 && k.beta < kInf; }
+  static M355_HD bool tab_ok(const K& k) { return k.alpha >= 0.01 && k.alpha <= 1e4 && k.beta > 0.0 && k.beta < kInf; }
   // (quantiles: ppf ~ q^(1/alpha) at the lower end, which no polynomial in logit q follows for alpha < 1)
   static constexpr bool kTabOkFn = true;
-  template <int FN> static bool tab_ok_fn(const K& k) { return (FN != M355_PPF && FN != M355_ISF) || k.alpha >= 1.0; }
+  template <int FN> static M355_HD bool tab_ok_fn(const K& k) { return (FN != M355_PPF && FN != M355_ISF) || k.alpha >= 1.0; }
   // (x is scaled by a power of two near beta / alpha first, so that |w| stays of the order of the spread of log x: for
   // large alpha the function is steep in w -- d log P / dw ~ sqrt(alpha) -- and log x itself would carry |log x| ulps;
   // alpha < 1: warped, see tab_warp)
   static M355_DEV double tab_w(double x, const K& k) {
     const double v = flog_tab_or_nan(x * k.tsc);
-    return k.alpha < 1.0 ? tab_warp(v) : v;
+    return tab_warp_if(k.alpha < 1.0, v);
   }
   static M355_DEV double tab_x(double w, const K& k) { return fdiv(exp_(k.alpha < 1.0 ? tab_unwarp(w) : w), k.tsc); }
   // gamma.py:77-82 with (alpha-1)*log(x) as xlogy0 (quirk Q2).
@@ -256,12 +256,12 @@ template <> struct Dist<M355_BETA> {
   }
   // beta.py:102-108; xlogy0(alpha+beta-1, 1) is a*log(1) == 0 (or the xlogy0 zero).
   // k_tab: the cdf family is tabulated in w = logit x (1 - x is exact for x >= 1/2); shapes below 1 as for gamma
-  static bool tab_ok(const K& k) { return k.a >= 0.01 && k.b >= 0.01 && k.a + k.b <= 500.0; }
+  static M355_HD bool tab_ok(const K& k) { return k.a >= 0.01 && k.b >= 0.01 && k.a + k.b <= 500.0; }
   // (quantiles as for gamma; logsf / sf with alpha < 1/2: the reference's betainc at the rounded 1 - x is a staircase
   // below x ~ 1e-6, where such a shape puts > 0.1 % of the data -- the cells there fail validation by design, and that
   // many misses cost more than the table saves)
   static constexpr bool kTabOkFn = true;
-  template <int FN> static bool tab_ok_fn(const K& k) {
+  template <int FN> static M355_HD bool tab_ok_fn(const K& k) {
     if (FN == M355_PPF || FN == M355_ISF) return k.a >= 1.0 && k.b >= 1.0;
     if (FN == M355_LOGSF || FN == M355_SF) return k.a >= 0.5;
     return true;
@@ -271,7 +271,7 @@ template <> struct Dist<M355_BETA> {
   static M355_HD double tab_cap(bool upper) { return upper ? 1.0 - 0x1p-53 : 0x1p-1000; }
   static M355_DEV double tab_w(double x, const K& k) {
     const double v = flog_tab_or_nan(fdiv_t<1, true>(x, 1.0 - x));
-    return tab_warped(k) ? tab_warp(v) : v;
+    return tab_warp_if(tab_warped(k), v);
   }
   static M355_DEV double tab_x(double w, const K& k) {
     // the smaller of x, 1 - x from exp(-|v|) (for |v| in the hundreds 1 / (1 + exp(-v)) would round to 1)
@@ -411,7 +411,7 @@ template <> struct Dist<M355_STUDENTT> {
   // those elements take the exact body, staircase included.  (Quantiles need no band: their parity is judged with the
   // modelled rounding of the reference's sqrt(1/b - 1), tests/harness.py _student_window.)
   // (nu <= 50: the band grows like nu -- 3 % of the mass at nu = 300 -- and the quantile's nodes get noisy with it)
-  static bool tab_ok(const K& k) { return k.nu >= 1.0 && k.nu <= 50.0 && k.sigma > 0.0 && k.sigma < kInf && k.mu - k.mu == 0.0; }
+  static M355_HD bool tab_ok(const K& k) { return k.nu >= 1.0 && k.nu <= 50.0 && k.sigma > 0.0 && k.sigma < kInf && k.mu - k.mu == 0.0; }
   static M355_DEV double tab_w(double x, const K& k) {
     const double z = fdiv_t<1, true>(x - k.mu, k.sigma), a = __builtin_fabs(z);
     const double w = flog_tab_or_nan(a + sqrt_(__builtin_fma(a, a, 1.0)));

@@ -605,7 +605,7 @@ template <> struct Dist<M355_INVERSEGAMMA> {
     return K{p[0], p[1], lga, p[0] * flog(p[1]) - lga};
   }
   // k_tab: log x, scaled by a power of two near alpha / beta (x ~ beta / Gamma(alpha))
-  static bool tab_ok(const K& k) { return k.alpha >= 1.0 && k.alpha <= 1e4 && k.beta > 0.0 && k.beta < kInf; }
+  static M355_HD bool tab_ok(const K& k) { return k.alpha >= 1.0 && k.alpha <= 1e4 && k.beta > 0.0 && k.beta < kInf; }
   static M355_DEV double tab_w(double x, const K& k) { return flog_tab_or_nan(x * pow2_near_inv(k.beta / k.alpha)); }
   static M355_DEV double tab_x(double w, const K& k) { return fdiv(exp_(w), pow2_near_inv(k.beta / k.alpha)); }
   // sum of logpdf with the logarithms carried as a product (m355_math.h LogProd; protocol of Dist<M355_GAMMA>::SumAcc)
@@ -663,7 +663,7 @@ template <> struct Dist<M355_CHISQUARED> {
     return cdf_bounds(gammainc_p(k.h, x / 2.0, k.lgh), x, 0.0, kInf);
   }
   // k_tab (m355_elemwise.h; the conditions are Dist<M355_GAMMA>'s with alpha = nu / 2)
-  static bool tab_ok(const K& k) { return k.nu >= 2.0 && k.nu <= 2e4; }
+  static M355_HD bool tab_ok(const K& k) { return k.nu >= 2.0 && k.nu <= 2e4; }
   static M355_DEV double tab_w(double x, const K& k) { return flog_tab_or_nan(x * pow2_near_inv(k.nu)); }
   static M355_DEV double tab_x(double w, const K& k) { return fdiv(exp_(w), pow2_near_inv(k.nu)); }
   // sum of logpdf with the logarithms carried as a product (m355_math.h LogProd; protocol of Dist<M355_GAMMA>::SumAcc)
@@ -722,7 +722,7 @@ template <> struct Dist<M355_SCALEDINVERSECHISQUARED> {
     return (x <= 0.0) ? 0.0 : flog(gammainc_p(k.h, k.ht / x, k.lgh));
   }
   // k_tab: log x, scaled by a power of two near 1 / tau2
-  static bool tab_ok(const K& k) { return k.nu >= 2.0 && k.nu <= 2e4 && k.tau2 > 0.0 && k.tau2 < kInf; }
+  static M355_HD bool tab_ok(const K& k) { return k.nu >= 2.0 && k.nu <= 2e4 && k.tau2 > 0.0 && k.tau2 < kInf; }
   static M355_DEV double tab_w(double x, const K& k) { return flog_tab_or_nan(x * pow2_near_inv(k.tau2)); }
   static M355_DEV double tab_x(double w, const K& k) { return fdiv(exp_(w), pow2_near_inv(k.tau2)); }
   // sum of logpdf with the logarithms carried as a product (m355_math.h LogProd; protocol of Dist<M355_GAMMA>::SumAcc)
@@ -828,7 +828,7 @@ template <> struct Dist<M355_BETASCALED> {
     return k;
   }
   // k_tab: logit of the position in (lower, upper), both differences formed from x directly (conditions as for beta)
-  static bool tab_ok(const K& k) { return k.a >= 1.0 && k.b >= 1.0 && k.a + k.b <= 500.0 && k.w > 0.0 && k.w < kInf; }
+  static M355_HD bool tab_ok(const K& k) { return k.a >= 1.0 && k.b >= 1.0 && k.a + k.b <= 500.0 && k.w > 0.0 && k.w < kInf; }
   static M355_DEV double tab_w(double x, const K& k) { return flog_tab_or_nan(fdiv_t<1, true>(x - k.lo, k.hi - x)); }
   static M355_DEV double tab_x(double w, const K& k) { return __builtin_fma(k.w, fdiv(1.0, 1.0 + exp_(-w)), k.lo); }
   // sum of logpdf: sum log(x - lo), sum log(hi - x) as LogProds (protocol of Dist<M355_GAMMA>::SumAcc)

@@ -633,6 +633,16 @@ constexpr int kColPer = 2;       // rows per thread
 constexpr int kColRows = kColPer * kBlock;  // rows per tile: 512 values per column = 8 wavefront passes (octiles of x)
 constexpr int kColBuckets = 64;
 
+typedef __attribute__((address_space(1))) double gdouble;  // a double in global memory (for pointers that arrive generic)
+M355_DEV long long uniform_ll(long long v) {  // v is wave-uniform: move it to scalar registers
+#if defined(__HIP_DEVICE_COMPILE__)
+  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(unsigned long long)v);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((unsigned long long)v >> 32));
+  return (long long)(((unsigned long long)hi << 32) | lo);
+#else
+  return v;
+#endif
+}
 M355_DEV double uniform_d(double v) {  // v is wave-uniform: move it to scalar registers
 #if defined(__HIP_DEVICE_COMPILE__)
   const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
@@ -865,6 +875,47 @@ struct ChebMono16 {
 };
 constexpr ChebMono16 kChebMono16{};
 
+// the function k_tab / k_coltab tabulate, at table variable w
+template <class DD, int FN> M355_DEV double tab_node_value(double w, const typename DD::K& k) {
+  constexpr bool QDOM = FN == M355_PPF || FN == M355_ISF;
+  double f;
+  if constexpr (QDOM && has_tab_node<DD>::value) {
+    f = DD::tab_ppf_node(w, k);
+  } else if constexpr (!QDOM && has_tab_fnode<DD>::value) {
+    f = DD::template tab_node<FN>(w, k);
+  } else if constexpr (QDOM) {
+    const double e = exp_(-__builtin_fabs(w));
+    const double p = fdiv(e, 1.0 + e);  // the smaller of q, 1 - q
+    if (w <= 0.0) {
+      f = DD::template eval<M355_PPF>(p, k);
+    } else {
+      f = DD::template eval<M355_PPF>(1.0 - p, k);
+      const double lp = flog(p);
+#pragma unroll 1
+      for (int it = 0; it < 2; ++it) {
+        const double lsf = DD::template eval<M355_LOGSF>(f, k);
+        const double step = (lsf - lp) * exp_(lsf - DD::template eval<M355_LOGPDF>(f, k));
+        if (step - step == 0.0) f += step;
+      }
+    }
+  } else {
+    f = DD::template eval<FN>(DD::tab_x(w, k), k);
+  }
+  return f;
+}
+// one end (upper: the right one) of the cdf family's table range
+template <class DD> M355_DEV double tab_range_end(bool upper, const typename DD::K& k) {
+  // (an end whose quantile is not a usable argument -- beta with b < 1: ppf(1 - 1e-9) rounds to 1 -- moves inwards)
+  double tq = kTabTailQ, we = kNaN;
+#pragma unroll 1
+  for (int it = 0; it < 4 && !(we - we == 0.0); ++it, tq *= 100.0)
+    we = DD::tab_w(DD::template eval<M355_PPF>(upper ? 1.0 - tq : tq, k), k);
+  if constexpr (has_tab_cap<DD>::value) {  // (still none: the outermost usable argument)
+    if (!(we - we == 0.0)) we = DD::tab_w(DD::tab_cap(upper), k);
+  }
+  return we;
+}
+
 template <int D, int FN> __device__ __noinline__ double tab_exact(double x, const typename Dist<D>::K& k) {
   return Dist<D>::template eval<FN>(x, k);
 }
@@ -887,15 +938,7 @@ __global__ __launch_bounds__(kBlock) void k_tab(const void* __restrict__ x, int 
     if constexpr (QDOM) {
       rng[threadIdx.x] = threadIdx.x == 0 ? -kTabLogitMax : kTabLogitMax;
     } else {
-      // (an end whose quantile is not a usable argument -- beta with b < 1: ppf(1 - 1e-9) rounds to 1 -- moves inwards)
-      double tq = kTabTailQ, we = kNaN;
-#pragma unroll 1
-      for (int it = 0; it < 4 && !(we - we == 0.0); ++it, tq *= 100.0)
-        we = DD::tab_w(DD::template eval<M355_PPF>(threadIdx.x == 0 ? tq : 1.0 - tq, k), k);
-      if constexpr (has_tab_cap<DD>::value) {  // (still none: the outermost usable argument)
-        if (!(we - we == 0.0)) we = DD::tab_w(DD::tab_cap(threadIdx.x == 1), k);
-      }
-      rng[threadIdx.x] = we;
+      rng[threadIdx.x] = tab_range_end<DD>(threadIdx.x == 1, k);
     }
   }
   if (threadIdx.x < 64) cosv[threadIdx.x] = kCos32[threadIdx.x];
@@ -907,29 +950,7 @@ __global__ __launch_bounds__(kBlock) void k_tab(const void* __restrict__ x, int 
   // node values: thread t takes (cell, node) = (j >> 4, j & 15) for j = t, t + 256, ...
   for (int j = threadIdx.x; j < kTabCells * kTabN; j += kBlock) {
     const double w = wlo + h * ((double)(j >> 4) + 0.5 + 0.5 * cosv[2 * (j & 15) + 1]);
-    double f;
-    if constexpr (QDOM && has_tab_node<DD>::value) {
-      f = DD::tab_ppf_node(w, k);
-    } else if constexpr (!QDOM && has_tab_fnode<DD>::value) {
-      f = DD::template tab_node<FN>(w, k);
-    } else if constexpr (QDOM) {
-      const double e = exp_(-__builtin_fabs(w));
-      const double p = fdiv(e, 1.0 + e);  // the smaller of q, 1 - q
-      if (w <= 0.0) {
-        f = DD::template eval<M355_PPF>(p, k);
-      } else {
-        f = DD::template eval<M355_PPF>(1.0 - p, k);
-        const double lp = flog(p);
-#pragma unroll 1
-        for (int it = 0; it < 2; ++it) {
-          const double lsf = DD::template eval<M355_LOGSF>(f, k);
-          const double step = (lsf - lp) * exp_(lsf - DD::template eval<M355_LOGPDF>(f, k));
-          if (step - step == 0.0) f += step;
-        }
-      }
-    } else {
-      f = DD::template eval<FN>(DD::tab_x(w, k), k);
-    }
+    const double f = tab_node_value<DD, FN>(w, k);
     coef[(j >> 4) * kTabStride + (j & 15)] = f;
   }
   __syncthreads();
@@ -1046,6 +1067,283 @@ __global__ __launch_bounds__(kBlock) void k_tab(const void* __restrict__ x, int 
     if (rv != rv) rv = tab_exact<D, FN>(xv, k);
     store1(out, odt, i, rv);
   }
+}
+
+// ---- The same tables for row-periodic parameters (x of shape (R, P), parameters of shape (P,)) ------------------------
+// A column of x shares one parameter set, so it can share one table.  A workgroup of 512 threads takes kCtCols = 16
+// adjacent columns (a row's 16 values are one 128-byte line) and a slice of the rows: it derives the 16 parameter sets,
+// builds their 16 tables (144 KiB of the CU's 160 KiB LDS, so one workgroup per CU; 16384 node evaluations, wave-uniform
+// parameters), and walks its rows with thread t on column t & 15 -- every thread keeps one table, one range and one
+// parameter set for the whole launch.  Validation, poisoning and misses as in k_tab; a column whose parameters
+// Dist<>::tab_ok declines gets an empty range, i.e. the exact body for all its elements.
+constexpr int kCtCols = 16, kCtBlock = 512, kCtRows = kCtBlock / kCtCols;
+// rows per thread and tile: eight for quantiles (the lookup needs no per-lane parameters), four for the cdf family (with
+// eight, the per-lane constants of tab_w on top of ~60 VGPRs per lookup in flight spill inside the loop)
+template <int FN> constexpr int ct_unroll() { return (FN == M355_PPF || FN == M355_ISF) ? 8 : 4; }
+constexpr int kCtTable = kTabCells * kTabStride;                      // doubles per table
+constexpr size_t kCtLds = (size_t)kCtCols * kCtTable * sizeof(double);  // dynamic LDS: 147456 B
+constexpr int kCtMaxNK = 12;
+
+// k_coltab's LDS, at namespace scope so that the row loop can live in a function of its own (coltab_rows) and still
+// address it as LDS
+extern __shared__ __attribute__((aligned(16))) double ct_coef[];  // [kCtCols][kTabCells][kTabStride]
+static __shared__ double ct_kt[kCtCols * kCtMaxNK];                // derived constants per column
+static __shared__ double ct_rng[2 * kCtCols];                      // table range per column
+
+// A thread's tile redone where the stored result is NaN (the mark of a miss; a NaN that the exact body itself returns
+// is simply recomputed).
+template <int D, int FN>
+__device__ __noinline__ void coltab_fixup(const void* x, int xdt, void* out, int odt, long long row0, long long R, long long P,
+                                          long long gcol, const double* kd) {
+  using K = typename Dist<D>::K;
+  constexpr int NK = sizeof(K) / sizeof(double);
+  K k;
+  double* dst = reinterpret_cast<double*>(&k);
+#pragma unroll
+  for (int f = 0; f < NK; ++f) dst[f] = kd[f];
+#pragma unroll 1
+  for (int u = 0; u < ct_unroll<FN>(); ++u) {
+    const long long row = row0 + u * kCtRows;
+    if (row < R) {
+      const long long idx = row * P + gcol;
+      const double o = load1(out, odt, (unsigned long long)idx);
+      if (o != o) store1(out, odt, idx, Dist<D>::template eval<FN>(load1(x, xdt, (unsigned long long)idx), k));
+    }
+  }
+}
+// (out of line: the build phase's heavy bodies must not shape the register allocation of the row loop)
+template <int D, int FN> __device__ __noinline__ double coltab_node(double w, const double* kd) {
+  using K = typename Dist<D>::K;
+  constexpr int NK = sizeof(K) / sizeof(double);
+  K k;
+  double* dst = reinterpret_cast<double*>(&k);
+#pragma unroll
+  for (int f = 0; f < NK; ++f) dst[f] = kd[f];
+  return tab_node_value<Dist<D>, FN>(w, k);
+}
+template <int D, int FN> __device__ __noinline__ double coltab_range_end(bool upper, const double* kd) {
+  using DD = Dist<D>;
+  using K = typename DD::K;
+  constexpr int NK = sizeof(K) / sizeof(double);
+  K k;
+  double* dst = reinterpret_cast<double*>(&k);
+#pragma unroll
+  for (int f = 0; f < NK; ++f) dst[f] = kd[f];
+  bool ok = DD::tab_ok(k);
+  if constexpr (has_tab_ok_fn<DD>::value) ok = ok && DD::template tab_ok_fn<FN>(k);
+  if (!ok) return kNaN;
+  if constexpr (FN == M355_PPF || FN == M355_ISF) return upper ? kTabLogitMax : -kTabLogitMax;
+  else return tab_range_end<DD>(upper, k);
+}
+
+// The row loop of k_coltab for one epoch (row blocks rbe, rbe + rbstep, ... at most 64 of them): looks every element up
+// in its column's table, stores the result (NaN where the table has nothing to say) and returns the set of row blocks in
+// which this thread met a NaN.
+template <int D, int FN, bool F64IO>
+__device__ __noinline__ unsigned long long coltab_rows(const void* __restrict__ x_, int xdt, void* __restrict__ out_, int odt,
+                                                       long long R, unsigned P, unsigned g, long long rbe, long long rbstep,
+                                                       long long row_blocks) {
+  using DD = Dist<D>;
+  using K = typename DD::K;
+  constexpr int NK = sizeof(K) / sizeof(double);
+  constexpr bool QDOM = FN == M355_PPF || FN == M355_ISF;
+  const int t = threadIdx.x;
+  // (function arguments arrive in vector registers: tell the compiler which are wavefront-uniform, and that the data
+  // pointers are global memory)
+  R = uniform_ll(R);
+  P = (unsigned)__builtin_amdgcn_readfirstlane((int)P);
+  g = (unsigned)__builtin_amdgcn_readfirstlane((int)g);
+  rbe = uniform_ll(rbe);
+  rbstep = uniform_ll(rbstep);
+  row_blocks = uniform_ll(row_blocks);
+  xdt = __builtin_amdgcn_readfirstlane(xdt);
+  odt = __builtin_amdgcn_readfirstlane(odt);
+  const void* x = reinterpret_cast<const void*>(uniform_ll(reinterpret_cast<long long>(x_)));
+  void* out = reinterpret_cast<void*>(uniform_ll(reinterpret_cast<long long>(out_)));
+  // this thread's column
+  const int col = t & (kCtCols - 1), rloc = t >> 4;
+  const double* mycoef = ct_coef + col * kCtTable;
+  const double* myk = ct_kt + col * kCtMaxNK;
+  K k;
+  {
+    double* kd = reinterpret_cast<double*>(&k);
+#pragma unroll
+    for (int f = 0; f < NK; ++f) kd[f] = myk[f];
+  }
+  const double wlo = ct_rng[2 * col], whi = ct_rng[2 * col + 1];
+  const double hh = (whi - wlo) * (1.0 / kTabCells);
+  const double inv_h = (hh > 0.0) ? 1.0 / hh : kNaN;
+  auto lookup = [&](double xv) -> double {
+    double wv;
+    if constexpr (QDOM) {
+      const double qq = (FN == M355_ISF) ? 1.0 - xv : xv;
+      wv = flog_tab_or_nan(fdiv_t<1, true>(qq, 1.0 - qq));
+      if constexpr (has_tab_node<DD>::value) wv = DD::tab_q_miss(qq) ? kNaN : wv;
+    } else {
+      wv = DD::tab_w(xv, k);
+    }
+    const double s_ = (wv - wlo) * inv_h;
+    const double fi = __builtin_floor(s_);
+    const bool in = (s_ >= 0.0) & (s_ < (double)kTabCells);
+    const double tt = __builtin_fma(2.0, s_ - fi, -1.0);
+    const d2_t* c = reinterpret_cast<const d2_t*>(mycoef + (in ? (int)fi : 0) * kTabStride);
+    d2_t cc = c[kTabN / 2 - 1];
+    double r = __builtin_fma(cc.y, tt, cc.x);
+#pragma unroll
+    for (int q = kTabN / 2 - 2; q >= 0; --q) {
+      cc = c[q];
+      r = __builtin_fma(__builtin_fma(r, tt, cc.y), tt, cc.x);
+    }
+    return in ? r : kNaN;
+  };
+  constexpr int kCtUnroll = ct_unroll<FN>();
+  constexpr int kRowsPerIter = kCtRows * kCtUnroll;
+  // addresses as a wavefront-uniform base (scalar registers) plus one 32-bit per-lane offset: sixteen 64-bit per-lane
+  // addresses would cost 32 VGPRs
+  const unsigned lane_off = (unsigned)rloc * P + (unsigned)col;  // elements; rloc < 32
+  unsigned long long missed = 0;
+  int it = 0;
+  for (long long rb = rbe; rb < row_blocks && it < 64; rb += rbstep, ++it) {
+    const long long ubase = rb * kRowsPerIter * (long long)P + (long long)g * kCtCols;  // uniform
+    const long long rows_left = R - rb * kRowsPerIter;                                 // uniform
+    double v[kCtUnroll], r[kCtUnroll];
+#pragma unroll
+    for (int u = 0; u < kCtUnroll; ++u) {
+      const long long ub = ubase + (long long)(u * kCtRows) * (long long)P;
+      const bool live = rloc < rows_left - u * kCtRows;
+      if constexpr (F64IO) v[u] = live ? ((const gdouble*)x + ub)[lane_off] : kNaN;
+      else v[u] = live ? load1(x, xdt, (unsigned long long)(ub + lane_off)) : kNaN;
+    }
+    bool miss = false;
+#pragma unroll
+    for (int u = 0; u < kCtUnroll; ++u) {
+      r[u] = lookup(v[u]);
+      miss |= r[u] != r[u];
+    }
+#pragma unroll
+    for (int u = 0; u < kCtUnroll; ++u) {
+      const long long ub = ubase + (long long)(u * kCtRows) * (long long)P;
+      const bool live = rloc < rows_left - u * kCtRows;
+      if constexpr (F64IO) {
+        if (live) ((gdouble*)out + ub)[lane_off] = r[u];
+      } else {
+        if (live) store1(out, odt, ub + lane_off, r[u]);
+      }
+    }
+    if (miss) missed |= 1ull << it;
+  }
+  return missed;
+}
+
+template <int D, int FN, bool F64IO>
+__global__ __launch_bounds__(kCtBlock) void k_coltab(const void* __restrict__ x, int xdt, void* __restrict__ out, int odt,
+                                                     long long R, unsigned P, PeriodicParams pa) {
+  using DD = Dist<D>;
+  using K = typename DD::K;
+  constexpr int NK = sizeof(K) / sizeof(double);
+  static_assert(NK <= kCtMaxNK, "k_coltab: K too large");
+  constexpr bool QDOM = FN == M355_PPF || FN == M355_ISF;
+  __shared__ double cosv[64];
+  __shared__ double tm[kTabN * kTabN];
+  __shared__ int bad[kTabCells];
+  const int t = threadIdx.x;
+  const unsigned G = P / kCtCols;
+  const unsigned g = blockIdx.x % G;                                  // this workgroup's column group
+  const long long rb0 = blockIdx.x / G, rbstep = gridDim.x / G;       // (gridDim.x is a multiple of G)
+  log_table_init();
+  if (t < kCtCols) {
+    double pp[kMaxParams];
+#pragma unroll
+    for (int q = 0; q < kMaxParams; ++q) pp[q] = (q < DD::NP && pa.ptr[q]) ? pa.ptr[q][g * kCtCols + t] : pa.scalar[q];
+    const K k = DD::derive(pp);
+    const double* kd = reinterpret_cast<const double*>(&k);
+#pragma unroll
+    for (int f = 0; f < NK; ++f) ct_kt[t * kCtMaxNK + f] = kd[f];
+  }
+  if (t < 64) cosv[t] = kCos32[t];
+  if (t < kTabN * kTabN) tm[t] = kChebMono16.t[t >> 4][t & 15];
+  __syncthreads();
+  if (t < 2 * kCtCols) ct_rng[t] = coltab_range_end<D, FN>((t & 1) != 0, ct_kt + (t >> 1) * kCtMaxNK);  // thread 2c + e
+  __syncthreads();
+  // node values of all tables: j = (table, cell, node); a wavefront's 64 nodes belong to one table
+  for (int j = t; j < kCtCols * kTabCells * kTabN; j += kCtBlock) {
+    const int c = j >> 10, jj = j & 1023;
+    const double wlo = ct_rng[2 * c], whi = ct_rng[2 * c + 1];
+    const double h = (whi - wlo) * (1.0 / kTabCells);
+    double f = kNaN;
+    if (h > 0.0) {  // (a declined column: nothing to evaluate)
+      const double w = wlo + h * ((double)(jj >> 4) + 0.5 + 0.5 * cosv[2 * (jj & 15) + 1]);
+      f = coltab_node<D, FN>(w, ct_kt + c * kCtMaxNK);
+    }
+    ct_coef[c * kCtTable + (jj >> 4) * kTabStride + (jj & 15)] = f;
+  }
+  __syncthreads();
+  // per table: DCT, validation, monomial basis (as k_tab; 1024 entries, two per thread)
+#pragma unroll 1
+  for (int c = 0; c < kCtCols; ++c) {
+    double* coef = ct_coef + c * kCtTable;
+    double cm[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int j = t + r * kCtBlock, cell = j >> 4, m = j & 15;
+      double acc = 0.0;
+#pragma unroll
+      for (int q = 0; q < kTabN; ++q) acc = __builtin_fma(coef[cell * kTabStride + q], cosv[(m * (2 * q + 1)) & 63], acc);
+      cm[r] = acc * (m == 0 ? 1.0 / 16.0 : 2.0 / 16.0);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int j = t + r * kCtBlock;
+      coef[(j >> 4) * kTabStride + (j & 15)] = cm[r];
+    }
+    __syncthreads();
+    if (t < kTabCells) {
+      const double* cc = coef + t * kTabStride;
+      double sum = 0.0;
+#pragma unroll
+      for (int q = 0; q < kTabN; ++q) sum += __builtin_fabs(cc[q]);
+      const double scale = (QDOM || sum > 1.0) ? sum : 1.0;
+      const double tail = __builtin_fabs(cc[14]) + __builtin_fabs(cc[15]);
+      bad[t] = !(tail <= kTabCoefTol * scale);
+    }
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int j = t + r * kCtBlock, cell = j >> 4, m = j & 15;
+      double acc = 0.0;
+#pragma unroll
+      for (int q = 0; q < kTabN; ++q) acc = __builtin_fma(coef[cell * kTabStride + q], tm[q * kTabN + m], acc);
+      cm[r] = acc;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int j = t + r * kCtBlock;
+      coef[(j >> 4) * kTabStride + (j & 15)] = ((j & 15) == 0 && bad[j >> 4]) ? kNaN : cm[r];
+    }
+    __syncthreads();
+  }
+  // rows, in epochs of up to 64 row blocks: coltab_rows (no calls inside: the register allocator is free there) marks
+  // misses with NaN and returns which of its row blocks had any; those are redone by coltab_fixup
+  constexpr int kCtUnroll = ct_unroll<FN>();
+  const long long row_blocks = (R + kCtRows * kCtUnroll - 1) / (kCtRows * kCtUnroll);
+  for (long long rbe = rb0; rbe < row_blocks; rbe += 64 * rbstep) {
+    unsigned long long mask = coltab_rows<D, FN, F64IO>(x, xdt, out, odt, R, P, g, rbe, rbstep, row_blocks);
+    const int col = t & (kCtCols - 1), rloc = t >> 4;
+    while (mask) {
+      const int i = __builtin_ctzll(mask);
+      mask &= mask - 1;
+      const long long rb = rbe + i * rbstep;
+      coltab_fixup<D, FN>(x, xdt, out, odt, rb * (kCtRows * kCtUnroll) + rloc, R, (long long)P, (long long)g * kCtCols + col,
+                          ct_kt + col * kCtMaxNK);
+    }
+  }
+}
+
+// k_coltab needs 144 KiB of dynamic LDS: above the 64 KiB a kernel gets without asking (per device, so asked per launch)
+template <int D, int FN, bool F64IO> bool coltab_ready() {
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_coltab<D, FN, F64IO>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                             (int)kCtLds) == hipSuccess;
 }
 
 // ---- Discrete families, scalar parameters, large n: the function of an integer, looked up ------------------------------
@@ -1369,10 +1667,35 @@ template <int D, int FN, bool REDUCE> int launch_fn(const LaunchArgs& a) {
     const void* xp = a.x.ptr;
     void* op = a.out;
     long long nn = n;
+    if constexpr (!REDUCE && tab_this<DD, FN>()) {
+      // row-periodic parameters, large n: per-column tables (k_coltab); the partial last row, if any, goes on below
+      const long long R = !all_scalar ? n / (long long)P : 0;
+      const unsigned long long G = P / kCtCols;
+      const bool f64 = a.x.dtype == M355_F64 && a.out_dtype == M355_F64;
+      if (P % kCtCols == 0 && G >= 1 && G <= 65536ull && R >= 1 && n / 8 >= tab_min_n() && !binning_disabled() &&
+          (f64 ? coltab_ready<D, FN, true>() : coltab_ready<D, FN, false>())) {
+        const long long row_blocks = (R + kCtRows * ct_unroll<FN>() - 1) / (kCtRows * ct_unroll<FN>());
+        long long m = (256 + (long long)G - 1) / (long long)G;  // one workgroup per CU (LDS)
+        m = m > row_blocks ? row_blocks : m;
+        if (f64)
+          hipLaunchKernelGGL((k_coltab<D, FN, true>), dim3((unsigned)(G * m)), dim3(kCtBlock), kCtLds, a.stream, xp, a.x.dtype, op,
+                             a.out_dtype, R, (unsigned)P, pa);
+        else
+          hipLaunchKernelGGL((k_coltab<D, FN, false>), dim3((unsigned)(G * m)), dim3(kCtBlock), kCtLds, a.stream, xp, a.x.dtype, op,
+                             a.out_dtype, R, (unsigned)P, pa);
+        const int rc = (int)hipGetLastError();
+        const long long done = R * (long long)P;
+        if (rc != 0 || done == n) return rc;
+        xp = static_cast<const char*>(xp) + done * (a.x.dtype == M355_F32 ? 4 : 8);
+        op = static_cast<char*>(op) + done * (a.out_dtype == M355_F32 ? 4 : 8);
+        nn = n - done;
+        blocks = 1;
+      }
+    }
     if constexpr (!REDUCE && bin_this<DD, FN>()) {
       // divergent functions with row-periodic parameters: whole blocks of kColRows rows go through k_colbinned (sorted
       // by x within each column); what is left (fewer than kColRows rows and a partial row) through k_periodic below
-      const long long row_blocks = !all_scalar ? (n / (long long)P) / kColRows : 0;
+      const long long row_blocks = !all_scalar ? (nn / (long long)P) / kColRows : 0;
       const unsigned long long G = P / kColW;
       if (row_blocks >= 4 && P % kColW == 0 && G <= (unsigned long long)kMaxBlocks && !binning_disabled()) {
         long long m = 2048 / (long long)G;
@@ -1381,10 +1704,10 @@ template <int D, int FN, bool REDUCE> int launch_fn(const LaunchArgs& a) {
                            a.out_dtype, row_blocks, (unsigned)P, pa);
         const int rc = (int)hipGetLastError();
         const long long done = row_blocks * kColRows * (long long)P;
-        if (rc != 0 || done == n) return rc;
+        if (rc != 0 || done == nn) return rc;
         xp = static_cast<const char*>(xp) + done * (a.x.dtype == M355_F32 ? 4 : 8);
         op = static_cast<char*>(op) + done * (a.out_dtype == M355_F32 ? 4 : 8);
-        nn = n - done;
+        nn -= done;
         const long long t2 = nn / kTile;
         blocks = (int)(t2 < 1 ? 1 : (t2 > blocks ? blocks : t2));
       }

@@ -65,6 +65,14 @@ M355_DEV double tab_warp(double v) {
   const double s = flog_tab_or_nan(a + sqrt_(__builtin_fma(a, a, 1.0)));
   return v < 0.0 ? -s : s;
 }
+// c ? tab_warp(v) : v behind a wavefront-uniform branch: with per-lane parameters (k_coltab) the compiler would
+// otherwise evaluate the warp for every element, whether or not any lane of the wavefront wants it
+M355_DEV double tab_warp_if(bool c, double v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  if (__builtin_amdgcn_ballot_w64(c) == 0) return v;
+#endif
+  return c ? tab_warp(v) : v;
+}
 M355_DEV double tab_unwarp(double s) {
   const double e = exp_(s);
   return 0.5 * (e - fdiv(1.0, e));

@@ -663,6 +663,114 @@ def test_colbinned_kernel_equals_periodic_kernel(gpu, name, fn, P):
     assert np.array_equal(flat[rows * P:], getattr(m, fn)(x[rows * P:], *tail_params), equal_nan=True)
 
 
+@pytest.mark.parametrize("name, fn, P", [("gamma", "logcdf", 1024), ("gamma", "ppf", 32), ("gamma", "sf", 48), ("beta", "logsf", 64),
+                                         ("beta", "cdf", 16), ("beta", "isf", 32), ("studentt", "logcdf", 32),
+                                         ("studentt", "ppf", 16), ("studentt", "logsf", 1024)])
+def test_coltab_kernel(gpu, name, fn, P):
+    """k_coltab (row-periodic parameters with P a multiple of 16: one Chebyshev table per column, 16 columns per
+    workgroup), forced onto a small input through m355_set_tab_min_n: against the oracle at the parity bar and against
+    the exact kernels (k_colbinned / k_periodic) at 5e-13 max(1, |b|) / 2e-13 relative for quantiles; special values
+    bit for bit; columns whose parameters Dist<>::tab_ok declines (the first three) come out exactly as the exact
+    kernels give them; the rows need not fill the last block of 256, and a partial last row goes through k_periodic."""
+    import ctypes
+
+    import torch
+
+    from distributions_amd import _lib
+    from distributions_amd._lib import DIST, F64, FN, Operand
+
+    L = _lib.lib()
+    nan, inf = np.nan, np.inf
+    rng = np.random.default_rng(77)
+    rows = 300 if P >= 1000 else 1111
+    tail = 5
+    n = rows * P + tail
+    quant = fn in ("ppf", "isf")
+    if name == "gamma":
+        params = (rng.uniform(1.0, 30.0, P), rng.uniform(0.2, 5.0, P))
+        if not quant:
+            params[0][P // 2:] = rng.uniform(0.05, 1.0, P - P // 2)  # warped tables
+        params[0][:3] = [0.004, 3e4, 0.5 if quant else 0.001]
+        draw = lambda: rng.gamma(params[0], 1.0 / params[1], (rows + 1, P))
+        special = [nan, inf, -inf, 0.0, -1.0, 5e-324, 1e300]
+    elif name == "beta":
+        params = (rng.uniform(1.0, 9.0, P), rng.uniform(1.0, 20.0, P))
+        if fn == "cdf":
+            params[1][P // 2:] = rng.uniform(0.1, 1.0, P - P // 2)
+        params[0][:3] = [0.004, 400.0, 0.3]
+        params[1][:3] = [2.0, 300.0, 2.0]
+        draw = lambda: rng.beta(params[0], params[1], (rows + 1, P))
+        special = [nan, inf, -inf, 0.0, 1.0, -0.5, 1.5, 5e-324]
+    else:
+        params = (rng.uniform(1.0, 50.0, P), rng.normal(0, 3, P), rng.uniform(0.1, 4.0, P))
+        params[0][:3] = [0.5, 80.0, 1e6]
+        draw = lambda: params[1] + params[2] * rng.standard_t(params[0], (rows + 1, P))
+        special = [nan, inf, -inf, 1e30, -1e30]
+    if quant:
+        x = rng.uniform(0, 1, (rows + 1, P))
+        x[1, :] = np.exp(rng.uniform(-20, 0, P))
+        x[2, :] = 1 - np.exp(rng.uniform(-20, 0, P))
+        special = [nan, 0.0, 1.0, -0.1, 1.1, 1e-300, 1e-12, 1 - 2.0**-53, 0.5]
+    else:
+        x = draw()
+    for j, sv in enumerate(special):
+        x[3 + j, :] = sv
+    x = np.ascontiguousarray(x).ravel()[:n]
+    xt = torch.from_numpy(x).to(gpu)
+    keep = [torch.from_numpy(np.ascontiguousarray(p)).to(gpu) for p in params]
+
+    def flat_call():
+        out = torch.empty(n, dtype=torch.float64, device=gpu)
+        ops = (Operand * (1 + len(params)))()
+        ops[0].ptr, ops[0].div, ops[0].mod, ops[0].dtype = xt.data_ptr(), 1, n, F64
+        for j, p in enumerate(keep, start=1):
+            ops[j].ptr, ops[j].scalar, ops[j].div, ops[j].mod, ops[j].dtype = p.data_ptr(), 0.0, 1, P, F64
+        at = lambda k: ctypes.cast(ctypes.byref(ops, k * ctypes.sizeof(Operand)), ctypes.POINTER(Operand))
+        _lib.check(L.m355_elemwise(DIST[name], FN[fn], F64, n, at(0), len(params), at(1), out.data_ptr(),
+                                   torch.cuda.current_stream(gpu).cuda_stream))
+        return out.cpu().numpy()
+
+    old = L.m355_set_tab_min_n(2**62)
+    try:
+        exact = flat_call()
+        L.m355_set_tab_min_n(1)
+        tab = flat_call()
+    finally:
+        L.m355_set_tab_min_n(old)
+    col = np.arange(n) % P
+    pfull = [np.resize(p, n) for p in params]
+    with np.errstate(all="ignore"):
+        exp = R.TABLE[f"{name}_{fn}"](x, *pfull)
+    assert np.array_equal(np.isnan(tab), np.isnan(exact))
+    declined = col < (2 if (name, fn) == ("beta", "cdf") else 3)  # (beta(0.3, 2).cdf is tabulated; its logsf / isf are not)
+    assert np.array_equal(tab[declined], exact[declined], equal_nan=True)
+    assert np.array_equal(tab[rows * P:], exact[rows * P:], equal_nan=True)  # the partial row
+    sp_rows = slice(3 * P, (3 + len(special)) * P)
+    if not quant:
+        assert np.array_equal(tab[sp_rows], exact[sp_rows], equal_nan=True)
+    fin = np.isfinite(exact)
+    if quant:
+        extra = np.zeros(n)
+        if name == "studentt":  # harness._student_window (the reference's sqrt(1/x - 1) next to the median), per element
+            with np.errstate(all="ignore"):
+                tt = np.abs((exp - pfull[1]) / pfull[2])
+                delta = tt * tt / (pfull[0] + tt * tt)
+                amp = np.where(delta > 0, 4 * 1.1e-16 / (2 * delta), 0.0) + 2e-16 * pfull[0]
+                extra = np.where(np.isfinite(tt), amp * tt * pfull[2], 0.0)
+            assert np.all(np.abs(tab[fin] - exact[fin]) <= 1e-12 * np.maximum(1.0, np.abs(exact[fin])) + extra[fin])
+        else:
+            assert np.all(np.abs(tab[fin] - exact[fin]) <= 2e-13 * np.abs(exact[fin]))
+        with np.errstate(all="ignore"):
+            ok = H.close(tab, exp) | (np.abs(tab - exp) <= 1e-12 * np.maximum(1.0, np.abs(exp)) + extra)
+        ok |= H.ppf_unpinned(name, fn, x) | ~np.isfinite(exp) | (tab == exact)
+    else:
+        assert np.all(np.abs(tab[fin] - exact[fin]) <= 5e-13 * np.maximum(1.0, np.abs(exact[fin])))
+        ok = H.close(tab, exp) | (tab == exact)
+    assert np.all(ok), (name, fn, x[~ok][:4], tab[~ok][:4], exp[~ok][:4])
+    used = ~declined & (np.arange(n) < rows * P)
+    assert np.mean(tab[used] == exact[used]) < 0.5  # the tables really were used
+
+
 def test_float32_arithmetic_bodies(gpu):
     """beta.logpdf on float32 data takes its two logarithms in float32 while the parameters are inside
     Dist<beta>::f32_ok (|alpha - 1|, |beta - 1| <= 8, |betaln| <= 12) and the float64 body outside: both within the
