@@ -1089,6 +1089,12 @@ constexpr int kCtMaxNK = 12;
 extern __shared__ __attribute__((aligned(16))) double ct_coef[];  // [kCtCols][kTabCells][kTabStride]
 static __shared__ double ct_kt[kCtCols * kCtMaxNK];                // derived constants per column
 static __shared__ double ct_rng[2 * kCtCols];                      // table range per column
+static __shared__ int ct_declined[kCtCols];                        // Dist<>::tab_ok / tab_ok_fn said no: k_coltab_declined's column
+template <class DD, int FN> M355_DEV bool coltab_params_ok(const typename DD::K& k) {
+  bool ok = DD::tab_ok(k);
+  if constexpr (has_tab_ok_fn<DD>::value) ok = ok && DD::template tab_ok_fn<FN>(k);
+  return ok;
+}
 
 // A thread's tile redone where the stored result is NaN (the mark of a miss; a NaN that the exact body itself returns
 // is simply recomputed).
@@ -1129,9 +1135,7 @@ template <int D, int FN> __device__ __noinline__ double coltab_range_end(bool up
   double* dst = reinterpret_cast<double*>(&k);
 #pragma unroll
   for (int f = 0; f < NK; ++f) dst[f] = kd[f];
-  bool ok = DD::tab_ok(k);
-  if constexpr (has_tab_ok_fn<DD>::value) ok = ok && DD::template tab_ok_fn<FN>(k);
-  if (!ok) return kNaN;
+  if (!coltab_params_ok<DD, FN>(k)) return kNaN;
   if constexpr (FN == M355_PPF || FN == M355_ISF) return upper ? kTabLogitMax : -kTabLogitMax;
   else return tab_range_end<DD>(upper, k);
 }
@@ -1173,6 +1177,9 @@ __device__ __noinline__ unsigned long long coltab_rows(const void* __restrict__ 
   const double wlo = ct_rng[2 * col], whi = ct_rng[2 * col + 1];
   const double hh = (whi - wlo) * (1.0 / kTabCells);
   const double inv_h = (hh > 0.0) ? 1.0 / hh : kNaN;
+  // no table for this column: k_coltab_declined does it, this loop leaves it alone.  (A column that was accepted but whose
+  // range came out empty -- not seen in practice -- has NaN lookups throughout: misses, redone by coltab_fixup.)
+  const bool declined = ct_declined[col] != 0;
   auto lookup = [&](double xv) -> double {
     double wv;
     if constexpr (QDOM) {
@@ -1210,7 +1217,7 @@ __device__ __noinline__ unsigned long long coltab_rows(const void* __restrict__ 
 #pragma unroll
     for (int u = 0; u < kCtUnroll; ++u) {
       const long long ub = ubase + (long long)(u * kCtRows) * (long long)P;
-      const bool live = rloc < rows_left - u * kCtRows;
+      const bool live = (rloc < rows_left - u * kCtRows) & !declined;
       if constexpr (F64IO) v[u] = live ? ((const gdouble*)x + ub)[lane_off] : kNaN;
       else v[u] = live ? load1(x, xdt, (unsigned long long)(ub + lane_off)) : kNaN;
     }
@@ -1223,14 +1230,14 @@ __device__ __noinline__ unsigned long long coltab_rows(const void* __restrict__ 
 #pragma unroll
     for (int u = 0; u < kCtUnroll; ++u) {
       const long long ub = ubase + (long long)(u * kCtRows) * (long long)P;
-      const bool live = rloc < rows_left - u * kCtRows;
+      const bool live = (rloc < rows_left - u * kCtRows) & !declined;
       if constexpr (F64IO) {
         if (live) ((gdouble*)out + ub)[lane_off] = r[u];
       } else {
         if (live) store1(out, odt, ub + lane_off, r[u]);
       }
     }
-    if (miss) missed |= 1ull << it;
+    if (miss & !declined) missed |= 1ull << it;
   }
   return missed;
 }
@@ -1259,6 +1266,7 @@ __global__ __launch_bounds__(kCtBlock) void k_coltab(const void* __restrict__ x,
     const double* kd = reinterpret_cast<const double*>(&k);
 #pragma unroll
     for (int f = 0; f < NK; ++f) ct_kt[t * kCtMaxNK + f] = kd[f];
+    ct_declined[t] = !coltab_params_ok<DD, FN>(k);
   }
   if (t < 64) cosv[t] = kCos32[t];
   if (t < kTabN * kTabN) tm[t] = kChebMono16.t[t >> 4][t & 15];
@@ -1337,6 +1345,41 @@ __global__ __launch_bounds__(kCtBlock) void k_coltab(const void* __restrict__ x,
       coltab_fixup<D, FN>(x, xdt, out, odt, rb * (kCtRows * kCtUnroll) + rloc, R, (long long)P, (long long)g * kCtCols + col,
                           ct_kt + col * kCtMaxNK);
     }
+  }
+}
+
+// Columns without a table (Dist<>::tab_ok / tab_ok_fn declined the parameters) are left
+// untouched by k_coltab and done by a second launch: P x kCtDeclChunks workgroups, each re-deriving its column's verdict
+// and returning at once unless the column was declined; a declined column's rows then go
+// through the exact body, parameters wavefront-uniform, spread over kCtDeclChunks workgroups.  (Inside k_coltab such
+// columns would be the work of the one workgroup that owns them: with a run of declined columns -- parameters sorted
+// along the row, a tenth of them out of range -- a handful of CUs did all of it, 58 ms per 1e8.)
+constexpr int kCtDeclChunks = 16;
+template <int D, int FN>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(min_waves<Dist<D>>::value))) void k_coltab_declined(
+    const void* __restrict__ x, int xdt, void* __restrict__ out, int odt, long long R, unsigned P, PeriodicParams pa) {
+  using DD = Dist<D>;
+  using K = typename DD::K;
+  constexpr int NK = sizeof(K) / sizeof(double);
+  const unsigned c = blockIdx.x % P, chunk = blockIdx.x / P;
+  double pp[kMaxParams];
+#pragma unroll
+  for (int q = 0; q < kMaxParams; ++q) pp[q] = (q < DD::NP && pa.ptr[q]) ? pa.ptr[q][c] : pa.scalar[q];
+  const K k0 = DD::derive(pp);  // (every thread: the same values, no barrier)
+  if (coltab_params_ok<DD, FN>(k0)) return;  // k_coltab has this column
+  log_table_init();
+  K k;
+  {
+    const double* kd = reinterpret_cast<const double*>(&k0);
+    double* dst = reinterpret_cast<double*>(&k);
+#pragma unroll
+    for (int f = 0; f < NK; ++f) dst[f] = uniform_d(kd[f]);
+  }
+  const long long per = (R + kCtDeclChunks - 1) / kCtDeclChunks;
+  const long long r1 = (chunk + 1) * per < R ? (chunk + 1) * per : R;
+  for (long long row = chunk * per + threadIdx.x; row < r1; row += kBlock) {
+    const long long idx = row * (long long)P + c;
+    store1(out, odt, idx, DD::template eval<FN>(load1(x, xdt, (unsigned long long)idx), k));
   }
 }
 
@@ -1683,6 +1726,8 @@ template <int D, int FN, bool REDUCE> int launch_fn(const LaunchArgs& a) {
         else
           hipLaunchKernelGGL((k_coltab<D, FN, false>), dim3((unsigned)(G * m)), dim3(kCtBlock), kCtLds, a.stream, xp, a.x.dtype, op,
                              a.out_dtype, R, (unsigned)P, pa);
+        hipLaunchKernelGGL((k_coltab_declined<D, FN>), dim3((unsigned)(P * kCtDeclChunks)), dim3(kBlock), 0, a.stream, xp, a.x.dtype,
+                           op, a.out_dtype, R, (unsigned)P, pa);
         const int rc = (int)hipGetLastError();
         const long long done = R * (long long)P;
         if (rc != 0 || done == n) return rc;
