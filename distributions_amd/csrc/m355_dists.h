@@ -155,9 +155,11 @@ template <> struct Dist<M355_GAMMA> {
   // k_tab (m355_elemwise.h): the cdf family is tabulated in w = log x.
   // Very large shapes neither: the exact bodies' own noise (~1e-16 alpha) then exceeds what a cell must show to be used.
   static M355_HD bool tab_ok(const K& k) { return k.alpha >= 0.01 && k.alpha <= 1e4 && k.beta > 0.0 && k.beta < kInf; }
-  // (quantiles: ppf ~ q^(1/alpha) at the lower end, which no polynomial in logit q follows for alpha < 1)
+  // (quantiles: ppf ~ q^(1/alpha) at the lower end, which no polynomial in logit q follows for alpha < 1: log(ppf) is
+  // tabulated instead, tab_ppf_log)
   static constexpr bool kTabOkFn = true;
-  template <int FN> static M355_HD bool tab_ok_fn(const K& k) { return (FN != M355_PPF && FN != M355_ISF) || k.alpha >= 1.0; }
+  template <int FN> static M355_HD bool tab_ok_fn(const K& k) { return (FN != M355_PPF && FN != M355_ISF) || k.alpha >= 0.05; }
+  static M355_HD bool tab_ppf_log(const K& k) { return k.alpha < 1.0; }  // (below 0.05, ppf(1e-9) underflows)
   // (x is scaled by a power of two near beta / alpha first, so that |w| stays of the order of the spread of log x: for
   // large alpha the function is steep in w -- d log P / dw ~ sqrt(alpha) -- and log x itself would carry |log x| ulps;
   // alpha < 1: warped, see tab_warp)
@@ -262,12 +264,13 @@ template <> struct Dist<M355_BETA> {
   // many misses cost more than the table saves)
   static constexpr bool kTabOkFn = true;
   template <int FN> static M355_HD bool tab_ok_fn(const K& k) {
-    if (FN == M355_PPF || FN == M355_ISF) return k.a >= 1.0 && k.b >= 1.0;
+    if (FN == M355_PPF || FN == M355_ISF) return k.a >= 0.05 && k.b >= 1.0;  // (b < 1: the upper nodes' Newton steps on logsf are ill-conditioned at x -> 1)
     if (FN == M355_LOGSF || FN == M355_SF) return k.a >= 0.5;
     return true;
   }
   static M355_HD bool tab_warped(const K& k) { return (k.a < 1.0) | (k.b < 1.0); }
   // (range ends when even ppf(1e-3) / ppf(1 - 1e-3) round to 0 / 1: the outermost doubles inside the support)
+  static M355_HD bool tab_ppf_log(const K& k) { return k.a < 1.0; }
   static M355_HD double tab_cap(bool upper) { return upper ? 1.0 - 0x1p-53 : 0x1p-1000; }
   static M355_DEV double tab_w(double x, const K& k) {
     const double v = flog_tab_or_nan(fdiv_t<1, true>(x, 1.0 - x));

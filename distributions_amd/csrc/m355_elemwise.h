@@ -830,6 +830,14 @@ template <class T, class = void> struct has_tab_node : std::false_type {};
 template <class T> struct has_tab_node<T, std::void_t<decltype(&T::tab_ppf_node)>> : std::true_type {};  // quantile nodes
 template <class T, class = void> struct has_tab_ok_fn : std::false_type {};  // per-function restrictions of tab_ok
 template <class T> struct has_tab_ok_fn<T, std::void_t<decltype(T::kTabOkFn)>> : std::true_type {};
+// Dist<>::tab_ppf_log(k): tabulate log(ppf) instead of ppf for these parameters (shapes below 1: ppf ~ q^(1/alpha) in the
+// lower tail, a straight line in logit q once the logarithm is taken); the lookup returns exp(table)
+template <class T, class = void> struct has_tab_ppf_log : std::false_type {};
+template <class T> struct has_tab_ppf_log<T, std::void_t<decltype(&T::tab_ppf_log)>> : std::true_type {};
+template <class DD, int FN> M355_DEV bool tab_log_mode(const typename DD::K& k) {
+  if constexpr ((FN == M355_PPF || FN == M355_ISF) && has_tab_ppf_log<DD>::value) return DD::tab_ppf_log(k);
+  else return false;
+}
 template <class T, class = void> struct has_tab_cap : std::false_type {};
 template <class T> struct has_tab_cap<T, std::void_t<decltype(&T::tab_cap)>> : std::true_type {};
 template <class T, class = void> struct has_tab_fnode : std::false_type {};
@@ -898,6 +906,7 @@ template <class DD, int FN> M355_DEV double tab_node_value(double w, const typen
         if (step - step == 0.0) f += step;
       }
     }
+    if (tab_log_mode<DD, FN>(k)) f = flog(f);
   } else {
     f = DD::template eval<FN>(DD::tab_x(w, k), k);
   }
@@ -980,7 +989,8 @@ __global__ __launch_bounds__(kBlock) void k_tab(const void* __restrict__ x, int 
     double sum = 0.0;
 #pragma unroll
     for (int q = 0; q < kTabN; ++q) sum += __builtin_fabs(c[q]);
-    const double scale = (QDOM || sum > 1.0) ? sum : 1.0;
+    // (log mode: an absolute error e of the table is a relative error e of the quantile: scale max(1, |log x|))
+    const double scale = ((QDOM && !tab_log_mode<DD, FN>(k)) || sum > 1.0) ? sum : 1.0;
     const double tail = __builtin_fabs(c[14]) + __builtin_fabs(c[15]);
     bad[threadIdx.x] = !(tail <= kTabCoefTol * scale);  // NaN / inf coefficients are bad too
   }
@@ -1022,6 +1032,7 @@ __global__ __launch_bounds__(kBlock) void k_tab(const void* __restrict__ x, int 
       cc = c[q];  // a_{2q}, a_{2q+1}
       r = __builtin_fma(__builtin_fma(r, t, cc.y), t, cc.x);
     }
+    if (tab_log_mode<DD, FN>(k)) r = exp_(r);  // (uniform)
     return in ? r : kNaN;
   };
   const long long ntiles = n / kTile;
@@ -1089,6 +1100,7 @@ constexpr int kCtMaxNK = 12;
 extern __shared__ __attribute__((aligned(16))) double ct_coef[];  // [kCtCols][kTabCells][kTabStride]
 static __shared__ double ct_kt[kCtCols * kCtMaxNK];                // derived constants per column
 static __shared__ double ct_rng[2 * kCtCols];                      // table range per column
+static __shared__ int ct_logmode[kCtCols];                         // quantile table holds log(ppf) (tab_log_mode)
 static __shared__ int ct_declined[kCtCols];                        // Dist<>::tab_ok / tab_ok_fn said no: k_coltab_declined's column
 template <class DD, int FN> M355_DEV bool coltab_params_ok(const typename DD::K& k) {
   bool ok = DD::tab_ok(k);
@@ -1180,6 +1192,7 @@ __device__ __noinline__ unsigned long long coltab_rows(const void* __restrict__ 
   // no table for this column: k_coltab_declined does it, this loop leaves it alone.  (A column that was accepted but whose
   // range came out empty -- not seen in practice -- has NaN lookups throughout: misses, redone by coltab_fixup.)
   const bool declined = ct_declined[col] != 0;
+  const bool logmode = ct_logmode[col] != 0;
   auto lookup = [&](double xv) -> double {
     double wv;
     if constexpr (QDOM) {
@@ -1200,6 +1213,9 @@ __device__ __noinline__ unsigned long long coltab_rows(const void* __restrict__ 
     for (int q = kTabN / 2 - 2; q >= 0; --q) {
       cc = c[q];
       r = __builtin_fma(__builtin_fma(r, tt, cc.y), tt, cc.x);
+    }
+    if constexpr (QDOM && has_tab_ppf_log<DD>::value) {
+      if (__builtin_amdgcn_ballot_w64(logmode) != 0) r = logmode ? exp_(r) : r;  // (skipped when no lane of the wavefront wants it)
     }
     return in ? r : kNaN;
   };
@@ -1267,6 +1283,7 @@ __global__ __launch_bounds__(kCtBlock) void k_coltab(const void* __restrict__ x,
 #pragma unroll
     for (int f = 0; f < NK; ++f) ct_kt[t * kCtMaxNK + f] = kd[f];
     ct_declined[t] = !coltab_params_ok<DD, FN>(k);
+    ct_logmode[t] = tab_log_mode<DD, FN>(k);
   }
   if (t < 64) cosv[t] = kCos32[t];
   if (t < kTabN * kTabN) tm[t] = kChebMono16.t[t >> 4][t & 15];
@@ -1311,7 +1328,7 @@ __global__ __launch_bounds__(kCtBlock) void k_coltab(const void* __restrict__ x,
       double sum = 0.0;
 #pragma unroll
       for (int q = 0; q < kTabN; ++q) sum += __builtin_fabs(cc[q]);
-      const double scale = (QDOM || sum > 1.0) ? sum : 1.0;
+      const double scale = ((QDOM && !ct_logmode[c]) || sum > 1.0) ? sum : 1.0;
       const double tail = __builtin_fabs(cc[14]) + __builtin_fabs(cc[15]);
       bad[t] = !(tail <= kTabCoefTol * scale);
     }

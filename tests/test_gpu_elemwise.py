@@ -436,7 +436,9 @@ def test_tabulated_kernel(gpu, name, params):
         tabulated = 1.0 <= params[0] <= 50.0
     else:
         tabulated = min(params) >= 0.01 and sum(params) <= 500.0
-    tabulated_q = tabulated and (name == "studentt" or min(params[:2] if name == "beta" else params[:1]) >= 1.0)
+    # quantiles: gamma from alpha = 0.05, beta from a = 0.05 with b >= 1 (shapes below 1 as tables of log(ppf): tab_ppf_log)
+    tabulated_q = tabulated and (name == "studentt" or (name == "gamma" and params[0] >= 0.05) or
+                                 (name == "beta" and params[0] >= 0.05 and params[1] >= 1.0))
     tabulated_all = tabulated
     for fn in ("logcdf", "logsf", "cdf", "sf"):
         # (beta.logsf / sf with alpha < 1/2 are left to the exact kernels: Dist<M355_BETA>::tab_ok_fn)
@@ -487,8 +489,10 @@ def test_tabulated_kernel(gpu, name, params):
         fin = np.isfinite(exact)
         if name == "studentt":  # next to the median the exact body follows the reference's quantised sqrt(1/b - 1)
             assert np.all(H.ppf_close(name, fn, params, tab[fin], exact[fin])), fn
-        else:
-            assert np.all(np.abs(tab[fin] - exact[fin]) <= 2e-13 * np.abs(exact[fin])), fn
+        else:  # (a table of log(ppf) carries its absolute error, ~1e-14 max(1, |log x|), as a relative error of x)
+            with np.errstate(all="ignore"):
+                lg = np.where(exact[fin] > 0, np.abs(np.log(np.where(exact[fin] > 0, exact[fin], 1.0))), 0.0)
+            assert np.all(np.abs(tab[fin] - exact[fin]) <= (2e-13 + 3e-14 * lg) * np.abs(exact[fin])), fn
         if tabulated_q:
             with np.errstate(all="ignore"):
                 exp = R.TABLE[f"{name}_{fn}"](q, *params)
@@ -688,9 +692,8 @@ def test_coltab_kernel(gpu, name, fn, P):
     quant = fn in ("ppf", "isf")
     if name == "gamma":
         params = (rng.uniform(1.0, 30.0, P), rng.uniform(0.2, 5.0, P))
-        if not quant:
-            params[0][P // 2:] = rng.uniform(0.05, 1.0, P - P // 2)  # warped tables
-        params[0][:3] = [0.004, 3e4, 0.5 if quant else 0.001]
+        params[0][P // 2:] = rng.uniform(0.05, 1.0, P - P // 2)  # warped tables / tables of log(ppf)
+        params[0][:3] = [0.004, 3e4, 0.03 if quant else 0.001]
         draw = lambda: rng.gamma(params[0], 1.0 / params[1], (rows + 1, P))
         special = [nan, inf, -inf, 0.0, -1.0, 5e-324, 1e300]
     elif name == "beta":
@@ -742,7 +745,7 @@ def test_coltab_kernel(gpu, name, fn, P):
     with np.errstate(all="ignore"):
         exp = R.TABLE[f"{name}_{fn}"](x, *pfull)
     assert np.array_equal(np.isnan(tab), np.isnan(exact))
-    declined = col < (2 if (name, fn) == ("beta", "cdf") else 3)  # (beta(0.3, 2).cdf is tabulated; its logsf / isf are not)
+    declined = col < (2 if (name, fn) in (("beta", "cdf"), ("beta", "isf")) else 3)  # (beta(0.3, 2): cdf and isf tabulated, logsf not)
     assert np.array_equal(tab[declined], exact[declined], equal_nan=True)
     assert np.array_equal(tab[rows * P:], exact[rows * P:], equal_nan=True)  # the partial row
     sp_rows = slice(3 * P, (3 + len(special)) * P)
@@ -759,7 +762,9 @@ def test_coltab_kernel(gpu, name, fn, P):
                 extra = np.where(np.isfinite(tt), amp * tt * pfull[2], 0.0)
             assert np.all(np.abs(tab[fin] - exact[fin]) <= 1e-12 * np.maximum(1.0, np.abs(exact[fin])) + extra[fin])
         else:
-            assert np.all(np.abs(tab[fin] - exact[fin]) <= 2e-13 * np.abs(exact[fin]))
+            with np.errstate(all="ignore"):
+                lg = np.where(exact[fin] > 0, np.abs(np.log(np.where(exact[fin] > 0, exact[fin], 1.0))), 0.0)
+            assert np.all(np.abs(tab[fin] - exact[fin]) <= (2e-13 + 3e-14 * lg) * np.abs(exact[fin]))
         with np.errstate(all="ignore"):
             ok = H.close(tab, exp) | (np.abs(tab - exp) <= 1e-12 * np.maximum(1.0, np.abs(exp)) + extra)
         ok |= H.ppf_unpinned(name, fn, x) | ~np.isfinite(exp) | (tab == exact)
