@@ -669,7 +669,8 @@ def test_colbinned_kernel_equals_periodic_kernel(gpu, name, fn, P):
 
 @pytest.mark.parametrize("name, fn, P", [("gamma", "logcdf", 1024), ("gamma", "ppf", 32), ("gamma", "sf", 48), ("beta", "logsf", 64),
                                          ("beta", "cdf", 16), ("beta", "isf", 32), ("studentt", "logcdf", 32),
-                                         ("studentt", "ppf", 16), ("studentt", "logsf", 1024)])
+                                         ("studentt", "ppf", 16), ("studentt", "logsf", 1024), ("inversegamma", "logcdf", 32),
+                                         ("inversegamma", "ppf", 16)])
 def test_coltab_kernel(gpu, name, fn, P):
     """k_coltab (row-periodic parameters with P a multiple of 16: one Chebyshev table per column, 16 columns per
     workgroup), forced onto a small input through m355_set_tab_min_n: against the oracle at the parity bar and against
@@ -695,6 +696,11 @@ def test_coltab_kernel(gpu, name, fn, P):
         params[0][P // 2:] = rng.uniform(0.05, 1.0, P - P // 2)  # warped tables / tables of log(ppf)
         params[0][:3] = [0.004, 3e4, 0.03 if quant else 0.001]
         draw = lambda: rng.gamma(params[0], 1.0 / params[1], (rows + 1, P))
+        special = [nan, inf, -inf, 0.0, -1.0, 5e-324, 1e300]
+    elif name == "inversegamma":  # (m355_dists2.h: tables for alpha in [1, 1e4])
+        params = (rng.uniform(1.0, 30.0, P), rng.uniform(0.2, 5.0, P))
+        params[0][:3] = [0.5, 3e4, 0.9]
+        draw = lambda: params[1] / rng.gamma(params[0], 1.0, (rows + 1, P))
         special = [nan, inf, -inf, 0.0, -1.0, 5e-324, 1e300]
     elif name == "beta":
         params = (rng.uniform(1.0, 9.0, P), rng.uniform(1.0, 20.0, P))
