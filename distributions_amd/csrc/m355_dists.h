@@ -271,7 +271,7 @@ template <> struct Dist<M355_BETA> {
   static M355_HD bool tab_warped(const K& k) { return (k.a < 1.0) | (k.b < 1.0); }
   // (range ends when even ppf(1e-3) / ppf(1 - 1e-3) round to 0 / 1: the outermost doubles inside the support)
   static M355_HD bool tab_ppf_log(const K& k) { return k.a < 1.0; }
-  static M355_HD double tab_cap(bool upper) { return upper ? 1.0 - 0x1p-53 : 0x1p-1000; }
+  static M355_HD double tab_cap(bool upper, const K&) { return upper ? 1.0 - 0x1p-53 : 0x1p-1000; }
   static M355_DEV double tab_w(double x, const K& k) {
     const double v = flog_tab_or_nan(fdiv_t<1, true>(x, 1.0 - x));
     return tab_warp_if(tab_warped(k), v);

@@ -777,6 +777,48 @@ template <> struct Dist<M355_HALFSTUDENTT> {
     k.ihalf_h = betainc_half(0.5 * p[0], 0.5, k.lbeta_h);
     return k;
   }
+  // ---- k_tab / k_coltab (m355_elemwise.h): cdf, sf and the quantiles ----
+  // As for studentt, the reference's cdf takes betainc at the rounded nu / (xn^2 + nu) (halfstudentt.py:76-83): next to
+  // 0 its values are quantised by 1.1e-16 / (B(1/2, nu/2) sqrt(y)), y = xn^2 / (xn^2 + nu).  The nodes come from the
+  // same function with y supplied (tab_node), and the band xn < 6e-4 sqrt(nu) / B where that quantisation exceeds a
+  // fifth of the parity bar is a miss (1.2e-3 / B^2 of the mass: 9e-4 at nu = 5).  logcdf divides the same error by the
+  // cdf -- its band would hold a percent of the mass -- and logsf = log1mexp(log cdf) does so in the upper tail: both
+  // stay on the exact kernels (tab_ok_fn).  Quantiles are judged on the absolute bar (1e-12 max(1, |x|)), which the
+  // reference's rounding of 1 - q next to q = 0 (relative 1e-16 / q of a quantile ~ q) never reaches: no band.
+  static M355_HD bool tab_ok(const K& k) { return k.nu >= 1.0 && k.nu <= 50.0 && k.sigma > 0.0 && k.sigma < kInf; }
+  static constexpr bool kTabOkFn = true;
+  template <int FN> static M355_HD bool tab_ok_fn(const K&) { return FN != M355_LOGCDF && FN != M355_LOGSF; }
+  static M355_DEV double tab_band(const K& k) { return 6e-4 * sqrt_(k.nu) * exp_(-k.lbeta_h); }
+  static M355_DEV double tab_w(double x, const K& k) {
+    const double xn = fdiv_t<1, true>(x, k.sigma);
+    return (xn < tab_band(k)) ? kNaN : flog_tab_or_nan(xn);
+  }
+  static M355_DEV double tab_x(double w, const K& k) { return k.sigma * exp_(w); }
+  // (the lower range end when ppf(1e-9 ... 1e-3) all fall inside the band: its edge)
+  static M355_DEV double tab_cap(bool upper, const K& k) { return upper ? kNaN : k.sigma * tab_band(k) * (1.0 + 0x1p-40); }
+  static constexpr bool kTabNode = true;
+  template <int FN> static M355_DEV double tab_node(double w, const K& k) {
+    const double xn = exp_(w);
+    const double d = __builtin_fma(xn, xn, k.nu);
+    const double xp = fdiv(k.nu, d), yp = fdiv(xn * xn, d);
+    constexpr bool UP = FN == M355_SF || FN == M355_LOGSF;
+    const double v = UP ? betainc_xy(0.5 * k.nu, 0.5, xp, yp, k.lbeta_h) : betainc_xy(0.5, 0.5 * k.nu, yp, xp, k.lbeta_h);
+    return (FN == M355_LOGCDF || FN == M355_LOGSF) ? flog(v) : v;
+  }
+  static M355_DEV bool tab_q_miss(double) { return false; }
+  // halfstudentt.py:94-101 takes betaincinv at 2 - 2 qf, qf = (q + 1) / 2: q + 1 rounds (1.1e-16 absolute, i.e.
+  // 1e-16 / (1 - q) of the upper-tail probability), and the reference's quantile is the smooth function of THAT
+  static M355_DEV double tab_q_den(double q) { return 2.0 - 2.0 * ((q + 1.0) / 2.0); }
+  // quantile at a node: p = sigmoid(-|w|) is the smaller of q, 1 - q; y = xn^2 / (xn^2 + nu) and b = 1 - y from whichever
+  // of I_y(1/2, nu/2) = q, I_b(nu/2, 1/2) = 1 - q has the small right-hand side; xn = sqrt(nu y / b)
+  static M355_DEV double tab_ppf_node(double w, const K& k) {
+    const double e = exp_(-__builtin_fabs(w));
+    const double p = fdiv(e, 1.0 + e);
+    double y, b;
+    if (w < 0.0) y = betaincinv_(0.5, 0.5 * k.nu, p, k.lbeta_h, 1.0 - k.ihalf_h, &b);
+    else b = betaincinv_(0.5 * k.nu, 0.5, p, k.lbeta_h, k.ihalf_h, &y);
+    return k.sigma * (sqrt_(k.nu) * sqrt_(fdiv(y, b)));
+  }
   static M355_DEV double cdf(double x, const K& k) {  // halfstudentt.py:76-83
     if (k.nu > 1e5) return halfnormal_cdf(x, k.sigma);
     const double xn = x / k.sigma;

@@ -838,6 +838,18 @@ template <class DD, int FN> M355_DEV bool tab_log_mode(const typename DD::K& k) 
   if constexpr ((FN == M355_PPF || FN == M355_ISF) && has_tab_ppf_log<DD>::value) return DD::tab_ppf_log(k);
   else return false;
 }
+// Dist<>::tab_q_den(q): the reference's own "1 - q" where its ppf forms it with a rounding of its own (halfstudentt:
+// 2 - 2 ((q + 1) / 2)); the quantile lookup then takes logit from (1 - den, den), i.e. follows the reference's argument
+template <class T, class = void> struct has_tab_q_den : std::false_type {};
+template <class T> struct has_tab_q_den<T, std::void_t<decltype(&T::tab_q_den)>> : std::true_type {};
+template <class DD> M355_DEV double tab_logit(double qq) {
+  double num = qq, den = 1.0 - qq;
+  if constexpr (has_tab_q_den<DD>::value) {
+    den = DD::tab_q_den(qq);
+    num = 1.0 - den;
+  }
+  return flog_tab_or_nan(fdiv_t<1, true>(num, den));
+}
 template <class T, class = void> struct has_tab_cap : std::false_type {};
 template <class T> struct has_tab_cap<T, std::void_t<decltype(&T::tab_cap)>> : std::true_type {};
 template <class T, class = void> struct has_tab_fnode : std::false_type {};
@@ -920,7 +932,7 @@ template <class DD> M355_DEV double tab_range_end(bool upper, const typename DD:
   for (int it = 0; it < 4 && !(we - we == 0.0); ++it, tq *= 100.0)
     we = DD::tab_w(DD::template eval<M355_PPF>(upper ? 1.0 - tq : tq, k), k);
   if constexpr (has_tab_cap<DD>::value) {  // (still none: the outermost usable argument)
-    if (!(we - we == 0.0)) we = DD::tab_w(DD::tab_cap(upper), k);
+    if (!(we - we == 0.0)) we = DD::tab_w(DD::tab_cap(upper, k), k);
   }
   return we;
 }
@@ -1015,7 +1027,7 @@ __global__ __launch_bounds__(kBlock) void k_tab(const void* __restrict__ x, int 
     double wv;
     if constexpr (QDOM) {
       const double qq = (FN == M355_ISF) ? 1.0 - xv : xv;
-      wv = flog_tab_or_nan(fdiv_t<1, true>(qq, 1.0 - qq));
+      wv = tab_logit<DD>(qq);
       if constexpr (has_tab_node<DD>::value) wv = DD::tab_q_miss(qq) ? kNaN : wv;
     } else {
       wv = DD::tab_w(xv, k);
@@ -1197,7 +1209,7 @@ __device__ __noinline__ unsigned long long coltab_rows(const void* __restrict__ 
     double wv;
     if constexpr (QDOM) {
       const double qq = (FN == M355_ISF) ? 1.0 - xv : xv;
-      wv = flog_tab_or_nan(fdiv_t<1, true>(qq, 1.0 - qq));
+      wv = tab_logit<DD>(qq);
       if constexpr (has_tab_node<DD>::value) wv = DD::tab_q_miss(qq) ? kNaN : wv;
     } else {
       wv = DD::tab_w(xv, k);

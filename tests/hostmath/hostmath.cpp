@@ -211,7 +211,7 @@ template <int D, int FN> static int tab_build(const double* p, double* out) {
       for (int it = 0; it < 4 && !(we - we == 0.0); ++it, tq *= 100.0)
         we = DD::tab_w(DD::template eval<M355_PPF>(e == 0 ? tq : 1.0 - tq, k), k);
       if constexpr (hm_has_cap<DD>::value) {
-        if (!(we - we == 0.0)) we = DD::tab_w(DD::tab_cap(e == 1), k);
+        if (!(we - we == 0.0)) we = DD::tab_w(DD::tab_cap(e == 1, k), k);
       }
       rng[e] = we;
     }

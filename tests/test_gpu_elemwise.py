@@ -403,7 +403,9 @@ def test_binomial_logpmf_large_counts(gpu, n, p):
                                           ("studentt", (5.0, 0.0, 2.0)), ("studentt", (1.0, 1.0, 0.5)),
                                           ("studentt", (30.0, -3.0, 1e-3)), ("studentt", (300.0, 0.0, 1.0)),
                                           ("studentt", (0.5, 0.0, 1.0)), ("gamma", (0.05, 2.0)), ("beta", (0.3, 4.0)),
-                                          ("beta", (3.0, 0.2)), ("gamma", (0.005, 1.0))])
+                                          ("beta", (3.0, 0.2)), ("gamma", (0.005, 1.0)), ("halfstudentt", (5.0, 2.0)),
+                                          ("halfstudentt", (1.0, 0.5)), ("halfstudentt", (40.0, 1e-2)),
+                                          ("halfstudentt", (80.0, 1.0))])
 def test_tabulated_kernel(gpu, name, params):
     """k_tab (per-launch Chebyshev tables of logcdf / logsf / cdf / sf for scalar parameters, m355_elemwise.h), forced
     onto a small input through m355_set_tab_min_n: against the oracle at the parity bar and against the exact kernels at
@@ -426,23 +428,29 @@ def test_tabulated_kernel(gpu, name, params):
         x = mu + sigma * rng.standard_t(nu, n)
         x[100:3000] = mu + sigma * rng.normal(0, 1e-3, 2900)  # the band around the centre and its edges
         special = np.array([nan, inf, -inf, mu, mu + 1e-9 * sigma, mu - 1e-7 * sigma, mu + 1e30 * sigma, mu - 1e30 * sigma])
+    elif name == "halfstudentt":  # cdf / sf / quantiles only; a band next to 0 stays exact (Dist<M355_HALFSTUDENTT>)
+        nu, sigma = params
+        x = sigma * np.abs(rng.standard_t(nu, n))
+        x[100:3000] = sigma * np.abs(rng.normal(0, 2e-3, 2900))  # the band next to 0 and its edge
+        special = np.array([nan, inf, -inf, 0.0, -1.0, 5e-324, 1e-9 * sigma, 1e30 * sigma])
     else:
         x = rng.beta(params[0], params[1], n)
         special = np.array([nan, inf, -inf, 0.0, 1.0, -0.5, 1.5, 5e-324, 1e-300, 1 - 2.0**-20, x.min() * 1e-6])
     x[: special.size] = special
     if name == "gamma":
         tabulated = 0.01 <= params[0] <= 1e4
-    elif name == "studentt":
+    elif name in ("studentt", "halfstudentt"):
         tabulated = 1.0 <= params[0] <= 50.0
     else:
         tabulated = min(params) >= 0.01 and sum(params) <= 500.0
     # quantiles: gamma from alpha = 0.05, beta from a = 0.05 with b >= 1 (shapes below 1 as tables of log(ppf): tab_ppf_log)
-    tabulated_q = tabulated and (name == "studentt" or (name == "gamma" and params[0] >= 0.05) or
+    tabulated_q = tabulated and (name in ("studentt", "halfstudentt") or (name == "gamma" and params[0] >= 0.05) or
                                  (name == "beta" and params[0] >= 0.05 and params[1] >= 1.0))
     tabulated_all = tabulated
     for fn in ("logcdf", "logsf", "cdf", "sf"):
         # (beta.logsf / sf with alpha < 1/2 are left to the exact kernels: Dist<M355_BETA>::tab_ok_fn)
         tabulated = tabulated_all and not (name == "beta" and fn in ("logsf", "sf") and params[0] < 0.5)
+        tabulated = tabulated and not (name == "halfstudentt" and fn in ("logcdf", "logsf"))
         old = L.m355_set_tab_min_n(2**62)
         try:
             exact = getattr(m, fn)(x, *params)
@@ -487,8 +495,10 @@ def test_tabulated_kernel(gpu, name, params):
         assert np.array_equal(tab[sp_], exact[sp_], equal_nan=True), (fn, specq, tab[sp_], exact[sp_])
         assert np.array_equal(np.isnan(tab), np.isnan(exact))
         fin = np.isfinite(exact)
-        if name == "studentt":  # next to the median the exact body follows the reference's quantised sqrt(1/b - 1)
-            assert np.all(H.ppf_close(name, fn, params, tab[fin], exact[fin])), fn
+        if name in ("studentt", "halfstudentt"):  # the exact body follows the reference's quantised sqrt(1/b - 1)
+            # (the window is modelled at the second argument: next to q = 0 halfstudentt's reference value can be 0
+            # itself -- b rounds to 1 -- so it is taken at whichever of the two is the smooth one)
+            assert np.all(H.ppf_close(name, fn, params, tab[fin], exact[fin]) | H.ppf_close(name, fn, params, exact[fin], tab[fin])), fn
         else:  # (a table of log(ppf) carries its absolute error, ~1e-14 max(1, |log x|), as a relative error of x)
             with np.errstate(all="ignore"):
                 lg = np.where(exact[fin] > 0, np.abs(np.log(np.where(exact[fin] > 0, exact[fin], 1.0))), 0.0)
@@ -496,7 +506,7 @@ def test_tabulated_kernel(gpu, name, params):
         if tabulated_q:
             with np.errstate(all="ignore"):
                 exp = R.TABLE[f"{name}_{fn}"](q, *params)
-            ok = H.ppf_close(name, fn, params, tab, exp) | H.ppf_unpinned(name, fn, q)
+            ok = H.ppf_close(name, fn, params, tab, exp) | H.ppf_close(name, fn, params, exp, tab) | H.ppf_unpinned(name, fn, q)
             assert np.all(ok | ~np.isfinite(exp)), (name, fn, params, q[~ok][:4], tab[~ok][:4], exp[~ok][:4])
             assert np.mean(tab == exact) < 0.5
         else:
