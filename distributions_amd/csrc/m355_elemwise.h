@@ -1744,7 +1744,12 @@ template <int D, int FN, bool REDUCE> int launch_fn(const LaunchArgs& a) {
       const long long R = !all_scalar ? n / (long long)P : 0;
       const unsigned long long G = P / kCtCols;
       const bool f64 = a.x.dtype == M355_F64 && a.out_dtype == M355_F64;
-      if (P % kCtCols == 0 && G >= 1 && G <= 65536ull && R >= 1 && n / 8 >= tab_min_n() && !binning_disabled() &&
+      // every workgroup builds 16 tables (16384 exact evaluations) for its 16 R / m elements: worth it from ~4 elements
+      // per node, i.e. 4096 rows per workgroup (scaled with m355_set_tab_min_n like the element threshold, so that tests
+      // can force the kernel onto small inputs; P = 1e6 columns of 100 rows stay on k_colbinned)
+      const double m0 = (double)((256 + G - 1) / (G ? G : 1));
+      const bool rows_ok = (double)R * (double)kTabMinN >= 4096.0 * m0 * (double)tab_min_n();
+      if (P % kCtCols == 0 && G >= 1 && G <= 65536ull && R >= 1 && rows_ok && n / 8 >= tab_min_n() && !binning_disabled() &&
           (f64 ? coltab_ready<D, FN, true>() : coltab_ready<D, FN, false>())) {
         const long long row_blocks = (R + kCtRows * ct_unroll<FN>() - 1) / (kCtRows * ct_unroll<FN>());
         long long m = (256 + (long long)G - 1) / (long long)G;  // one workgroup per CU (LDS)

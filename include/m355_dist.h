@@ -141,11 +141,12 @@ int m355_elemwise(int dist, int fn, int out_dtype, int64_t n, const m355_operand
 
 /*
  * Tuning knob of m355_elemwise, no counterpart in the reference.  With scalar parameters and at least `min_n`
- * elements, logcdf / logsf / cdf / sf / ppf / isf of gamma, beta, studentt (and chisquared, inversegamma,
+ * elements, logcdf / logsf / cdf / sf / ppf / isf of gamma, beta, studentt (and halfstudentt, chisquared, inversegamma,
  * scaledinversechisquared, betascaled) are evaluated from a table that every workgroup builds from the exact bodies at
  * launch (k_tab; cells that do not reach 1e-14 and arguments outside the table take the exact
  * body), and the same functions of the discrete families from tables of the exact values over a window of integers
- * (k_dtab: bit-identical results).  Returns the previous threshold; min_n < 0 restores the default (2^21),
+ * (k_dtab: bit-identical results).  With row-periodic parameters (x of shape (R, P), parameters of shape (P,), P a
+ * multiple of 16) the same tables are built per column from 8 * min_n elements (k_coltab).  Returns the previous threshold; min_n < 0 restores the default (2^21),
  * INT64_MAX switches the table off.  Process-wide, not synchronised with launches in flight on other threads.
  */
 int64_t m355_set_tab_min_n(int64_t min_n);
