@@ -777,33 +777,35 @@ template <> struct Dist<M355_HALFSTUDENTT> {
     k.ihalf_h = betainc_half(0.5 * p[0], 0.5, k.lbeta_h);
     return k;
   }
-  // ---- k_tab / k_coltab (m355_elemwise.h): cdf, sf and the quantiles ----
-  // As for studentt, the reference's cdf takes betainc at the rounded nu / (xn^2 + nu) (halfstudentt.py:76-83): next to
-  // 0 its values are quantised by 1.1e-16 / (B(1/2, nu/2) sqrt(y)), y = xn^2 / (xn^2 + nu).  The nodes come from the
-  // same function with y supplied (tab_node), and the band xn < 6e-4 sqrt(nu) / B where that quantisation exceeds a
-  // fifth of the parity bar is a miss (1.2e-3 / B^2 of the mass: 9e-4 at nu = 5).  logcdf divides the same error by the
-  // cdf -- its band would hold a percent of the mass -- and logsf = log1mexp(log cdf) does so in the upper tail: both
-  // stay on the exact kernels (tab_ok_fn).  Quantiles are judged on the absolute bar (1e-12 max(1, |x|)), which the
-  // reference's rounding of 1 - q next to q = 0 (relative 1e-16 / q of a quantile ~ q) never reaches: no band.
+  // ---- k_tab / k_coltab (m355_elemwise.h) ----
+  // The reference's cdf is 1 - I_{x'}(nu/2, 1/2) at x' = nu / (xn^2 + nu) (halfstudentt.py:76-83), and x' rounds: next
+  // to 0 the cdf is a staircase in x (1.1e-16 / (B(1/2, nu/2) sqrt(1 - x')) per step) -- but a smooth function of the
+  // ROUNDED x'.  The table variable is therefore w = log(u / x') with x' formed exactly as the exact body forms it and
+  // u = 1 - x' (exact for x' >= 1/2): a lookup lands on the reference's own step, and the nodes are I_u(1/2, nu/2) with
+  // u supplied.  What is left is the rounding of (1 - f) 2 - 1 itself, 2e-16 absolute on the cdf: logcdf carries it
+  // divided by the cdf and logsf = log1mexp(log cdf) divided by the sf, so table values below log(1e-4) resp.
+  // log(4e-4) -- where that exceeds a fifth of the parity bar -- are misses (tab_value_miss: 1e-4 / 4e-4 of the mass).
+  // Quantiles are judged with the modelled rounding of sqrt(nu / b - nu) (tests/harness.py _student_window): no band.
   static M355_HD bool tab_ok(const K& k) { return k.nu >= 1.0 && k.nu <= 50.0 && k.sigma > 0.0 && k.sigma < kInf; }
-  static constexpr bool kTabOkFn = true;
-  template <int FN> static M355_HD bool tab_ok_fn(const K&) { return FN != M355_LOGCDF && FN != M355_LOGSF; }
-  static M355_DEV double tab_band(const K& k) { return 6e-4 * sqrt_(k.nu) * exp_(-k.lbeta_h); }
   static M355_DEV double tab_w(double x, const K& k) {
-    const double xn = fdiv_t<1, true>(x, k.sigma);
-    return (xn < tab_band(k)) ? kNaN : flog_tab_or_nan(xn);
+    const double xn = x / k.sigma;
+    const double xp = k.nu / (xn * xn + k.nu);  // (IEEE divisions, as in cdf() below: this rounding IS the staircase)
+    return (xn > 0.0) ? flog_tab_or_nan(fdiv_t<1, true>(1.0 - xp, xp)) : kNaN;  // (xn^2 forgets the sign: x <= 0 is a miss)
   }
-  static M355_DEV double tab_x(double w, const K& k) { return k.sigma * exp_(w); }
-  // (the lower range end when ppf(1e-9 ... 1e-3) all fall inside the band: its edge)
-  static M355_DEV double tab_cap(bool upper, const K& k) { return upper ? kNaN : k.sigma * tab_band(k) * (1.0 + 0x1p-40); }
+  static M355_DEV double tab_x(double w, const K& k) { return k.sigma * sqrt_(k.nu * exp_(w)); }  // u / x' = xn^2 / nu
   static constexpr bool kTabNode = true;
   template <int FN> static M355_DEV double tab_node(double w, const K& k) {
-    const double xn = exp_(w);
-    const double d = __builtin_fma(xn, xn, k.nu);
-    const double xp = fdiv(k.nu, d), yp = fdiv(xn * xn, d);
+    const double e = exp_(-__builtin_fabs(w));
+    const double sm = fdiv(e, 1.0 + e);
+    const double u = (w < 0.0) ? sm : 1.0 - sm, xp = (w < 0.0) ? 1.0 - sm : sm;
     constexpr bool UP = FN == M355_SF || FN == M355_LOGSF;
-    const double v = UP ? betainc_xy(0.5 * k.nu, 0.5, xp, yp, k.lbeta_h) : betainc_xy(0.5, 0.5 * k.nu, yp, xp, k.lbeta_h);
+    const double v = UP ? betainc_xy(0.5 * k.nu, 0.5, xp, u, k.lbeta_h) : betainc_xy(0.5, 0.5 * k.nu, u, xp, k.lbeta_h);
     return (FN == M355_LOGCDF || FN == M355_LOGSF) ? flog(v) : v;
+  }
+  template <int FN> static M355_DEV bool tab_value_miss(double r) {
+    if (FN == M355_LOGCDF) return r < -9.210340371976182;  // log(1e-4)
+    if (FN == M355_LOGSF) return r < -7.824046010856292;   // log(4e-4)
+    return false;
   }
   static M355_DEV bool tab_q_miss(double) { return false; }
   // halfstudentt.py:94-101 takes betaincinv at 2 - 2 qf, qf = (q + 1) / 2: q + 1 rounds (1.1e-16 absolute, i.e.

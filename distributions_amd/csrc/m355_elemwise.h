@@ -850,6 +850,10 @@ template <class DD> M355_DEV double tab_logit(double qq) {
   }
   return flog_tab_or_nan(fdiv_t<1, true>(num, den));
 }
+// Dist<>::tab_value_miss<FN>(r): table values the reference does not reach within the parity bar (its own rounding
+// noise, e.g. log of a difference of O(1) numbers): a miss, i.e. the exact body's reproduction of that arithmetic
+template <class T, class = void> struct has_tab_value_miss : std::false_type {};
+template <class T> struct has_tab_value_miss<T, std::void_t<decltype(&T::template tab_value_miss<M355_LOGCDF>)>> : std::true_type {};
 template <class T, class = void> struct has_tab_cap : std::false_type {};
 template <class T> struct has_tab_cap<T, std::void_t<decltype(&T::tab_cap)>> : std::true_type {};
 template <class T, class = void> struct has_tab_fnode : std::false_type {};
@@ -1045,6 +1049,7 @@ __global__ __launch_bounds__(kBlock) void k_tab(const void* __restrict__ x, int 
       r = __builtin_fma(__builtin_fma(r, t, cc.y), t, cc.x);
     }
     if (tab_log_mode<DD, FN>(k)) r = exp_(r);  // (uniform)
+    if constexpr (has_tab_value_miss<DD>::value) r = DD::template tab_value_miss<FN>(r) ? kNaN : r;
     return in ? r : kNaN;
   };
   const long long ntiles = n / kTile;
@@ -1229,6 +1234,7 @@ __device__ __noinline__ unsigned long long coltab_rows(const void* __restrict__ 
     if constexpr (QDOM && has_tab_ppf_log<DD>::value) {
       if (__builtin_amdgcn_ballot_w64(logmode) != 0) r = logmode ? exp_(r) : r;  // (skipped when no lane of the wavefront wants it)
     }
+    if constexpr (has_tab_value_miss<DD>::value) r = DD::template tab_value_miss<FN>(r) ? kNaN : r;
     return in ? r : kNaN;
   };
   constexpr int kCtUnroll = ct_unroll<FN>();

@@ -13,7 +13,7 @@ def t(f):
 for nu, sg in ((5.0, 2.0), (1.0, 1.0), (30.0, 0.5)):
     x = (torch.distributions.StudentT(torch.tensor(nu, dtype=torch.float64, device=dev)).sample((n,)).abs() * sg)
     q = torch.rand(n, dtype=torch.float64, device=dev)
-    for fn in ("cdf", "sf", "ppf", "logcdf"):
+    for fn in ("cdf", "sf", "ppf", "logcdf", "logsf"):
         f = getattr(halfstudentt, fn); arg = q if fn == "ppf" else x
         L.m355_set_tab_min_n(2**59); exact = f(arg, nu, sg); te = t(lambda: f(arg, nu, sg))
         L.m355_set_tab_min_n(2**21); tab = f(arg, nu, sg); tt = t(lambda: f(arg, nu, sg))

@@ -428,7 +428,7 @@ def test_tabulated_kernel(gpu, name, params):
         x = mu + sigma * rng.standard_t(nu, n)
         x[100:3000] = mu + sigma * rng.normal(0, 1e-3, 2900)  # the band around the centre and its edges
         special = np.array([nan, inf, -inf, mu, mu + 1e-9 * sigma, mu - 1e-7 * sigma, mu + 1e30 * sigma, mu - 1e30 * sigma])
-    elif name == "halfstudentt":  # cdf / sf / quantiles only; a band next to 0 stays exact (Dist<M355_HALFSTUDENTT>)
+    elif name == "halfstudentt":  # tabulated in the reference's own rounded nu / (xn^2 + nu) (Dist<M355_HALFSTUDENTT>)
         nu, sigma = params
         x = sigma * np.abs(rng.standard_t(nu, n))
         x[100:3000] = sigma * np.abs(rng.normal(0, 2e-3, 2900))  # the band next to 0 and its edge
@@ -450,7 +450,6 @@ def test_tabulated_kernel(gpu, name, params):
     for fn in ("logcdf", "logsf", "cdf", "sf"):
         # (beta.logsf / sf with alpha < 1/2 are left to the exact kernels: Dist<M355_BETA>::tab_ok_fn)
         tabulated = tabulated_all and not (name == "beta" and fn in ("logsf", "sf") and params[0] < 0.5)
-        tabulated = tabulated and not (name == "halfstudentt" and fn in ("logcdf", "logsf"))
         old = L.m355_set_tab_min_n(2**62)
         try:
             exact = getattr(m, fn)(x, *params)
