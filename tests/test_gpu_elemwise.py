@@ -789,6 +789,34 @@ def test_coltab_kernel(gpu, name, fn, P):
     assert np.all(ok), (name, fn, x[~ok][:4], tab[~ok][:4], exp[~ok][:4])
     used = ~declined & (np.arange(n) < rows * P)
     assert np.mean(tab[used] == exact[used]) < 0.5  # the tables really were used
+    if (name, fn) in (("gamma", "logcdf"), ("beta", "isf")):  # float32 in / out through the same kernel (generic loads)
+        from distributions_amd._lib import F32
+
+        with np.errstate(over="ignore"):  # (1e300 -> inf)
+            x32 = torch.from_numpy(x.astype(np.float32)).to(gpu)
+
+        def flat_call32():
+            out = torch.empty(n, dtype=torch.float32, device=gpu)
+            ops = (Operand * (1 + len(params)))()
+            ops[0].ptr, ops[0].div, ops[0].mod, ops[0].dtype = x32.data_ptr(), 1, n, F32
+            for j, p in enumerate(keep, start=1):
+                ops[j].ptr, ops[j].scalar, ops[j].div, ops[j].mod, ops[j].dtype = p.data_ptr(), 0.0, 1, P, F64
+            at = lambda k: ctypes.cast(ctypes.byref(ops, k * ctypes.sizeof(Operand)), ctypes.POINTER(Operand))
+            _lib.check(L.m355_elemwise(DIST[name], FN[fn], F32, n, at(0), len(params), at(1), out.data_ptr(),
+                                       torch.cuda.current_stream(gpu).cuda_stream))
+            return out.cpu().numpy().astype(np.float64)
+
+        old = L.m355_set_tab_min_n(2**62)
+        try:
+            exact32 = flat_call32()
+            L.m355_set_tab_min_n(1)
+            tab32 = flat_call32()
+        finally:
+            L.m355_set_tab_min_n(old)
+        assert np.array_equal(np.isnan(tab32), np.isnan(exact32))
+        fin = np.isfinite(exact32)
+        assert np.array_equal(np.isinf(tab32), np.isinf(exact32))
+        assert np.all(np.abs(tab32[fin] - exact32[fin]) <= 1e-5 * np.maximum(1.0, np.abs(exact32[fin])))
 
 
 def test_float32_arithmetic_bodies(gpu):
