@@ -513,6 +513,64 @@ def test_tabulated_kernel(gpu, name, params):
     assert L.m355_set_tab_min_n(-1) == old and L.m355_set_tab_min_n(old) == 2**21
 
 
+@pytest.mark.parametrize("name, params", [("chisquared", (7.0,)), ("chisquared", (300.0,)), ("inversegamma", (3.0, 2.0)),
+                                          ("inversegamma", (40.0, 1e3)), ("scaledinversechisquared", (5.0, 0.7)),
+                                          ("betascaled", (2.0, 5.0, -1.0, 3.0)), ("betascaled", (30.0, 1.5, 10.0, 10.5))])
+def test_tabulated_kernel_relatives(gpu, name, params):
+    """k_tab for the families of m355_dists2.h that share gamma's and beta's table variables (chisquared, inversegamma,
+    scaledinversechisquared: log of the scaled argument; betascaled: logit of the standardised one): all six functions
+    against the exact kernels (5e-13 max(1, |b|), quantiles 2e-13 relative) and the oracle (parity bar), NaN / infinities /
+    out-of-support points bit for bit, and the table really in use."""
+    from distributions_amd import _lib
+
+    L = _lib.lib()
+    rng = np.random.default_rng(35)
+    m = mod(name)
+    n = 30_000 + 11
+    if name == "chisquared":
+        x = rng.chisquare(params[0], n)
+    elif name == "inversegamma":
+        x = params[1] / rng.gamma(params[0], 1.0, n)
+    elif name == "scaledinversechisquared":
+        x = params[0] * params[1] / rng.chisquare(params[0], n)
+    else:
+        x = params[2] + (params[3] - params[2]) * rng.beta(params[0], params[1], n)
+    lo, hi = (params[2], params[3]) if name == "betascaled" else (0.0, np.inf)
+    special = np.array([np.nan, np.inf, -np.inf, lo, lo - 1.0, hi if np.isfinite(hi) else 1e300, (hi if np.isfinite(hi) else 1e300) + 1.0])
+    x[: special.size] = special
+    q = rng.uniform(0, 1, n)
+    q[:1000] = np.exp(rng.uniform(-18, 0, 1000))
+    q[1000:2000] = 1 - np.exp(rng.uniform(-18, 0, 1000))
+    specq = np.array([np.nan, 0.0, 1.0, -0.1, 1.1])
+    q[2000:2005] = specq
+    for fn in ("logcdf", "logsf", "cdf", "sf", "ppf", "isf"):
+        quant = fn in ("ppf", "isf")
+        arg = q if quant else x
+        old = L.m355_set_tab_min_n(2**62)
+        try:
+            exact = getattr(m, fn)(arg, *params)
+            L.m355_set_tab_min_n(1)
+            tab = getattr(m, fn)(arg, *params)
+        finally:
+            L.m355_set_tab_min_n(old)
+        with np.errstate(all="ignore"):
+            exp = R.TABLE[f"{name}_{fn}"](arg, *params)
+        assert np.array_equal(np.isnan(tab), np.isnan(exact)), fn
+        sp_ = slice(2000, 2005) if quant else slice(0, special.size)
+        assert np.array_equal(tab[sp_], exact[sp_], equal_nan=True), (fn, tab[sp_], exact[sp_])
+        fin = np.isfinite(exact)
+        if quant:
+            assert np.all(np.abs(tab[fin] - exact[fin]) <= 2e-13 * np.maximum(np.abs(exact[fin]), 1e-300) + 1e-13 * (hi - lo if np.isfinite(hi) else 0.0)), fn
+            ok = H.ppf_close(name, fn, params, tab, exp) | H.ppf_unpinned(name, fn, arg) | ~np.isfinite(exp) | (tab == exact)
+        else:
+            assert np.all(np.abs(tab[fin] - exact[fin]) <= 5e-13 * np.maximum(1.0, np.abs(exact[fin]))), fn
+            ok = H.close(tab, exp) | H.family_ok(name, fn, tab, exp, params) | (tab == exact)
+        assert np.all(ok), (name, fn, params, arg[~ok][:4], tab[~ok][:4], exp[~ok][:4])
+        # (betascaled on [10, 10.5]: x carries ulp(10) / 0.5 = 4e-15 of the standardised variable, times the slope ~ a = 30:
+        # half the cells cannot show 1e-14 and are poisoned -- those elements are misses, by design)
+        assert np.mean(tab == exact) < (0.9 if params[-1] == 10.5 else 0.5), fn
+
+
 @pytest.mark.parametrize("name, params", [("poisson", (100.0,)), ("poisson", (0.7,)), ("binomial", (1000.0, 0.3)),
                                           ("binomial", (12.0, 0.9)), ("negativebinomial", (10.0, 0.1)),
                                           ("betabinomial", (100.0, 20.0, 20.0)), ("hypergeometric", (50.0, 20.0, 10.0)),
