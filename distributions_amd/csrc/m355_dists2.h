@@ -605,9 +605,16 @@ template <> struct Dist<M355_INVERSEGAMMA> {
     return K{p[0], p[1], lga, p[0] * flog(p[1]) - lga};
   }
   // k_tab: log x, scaled by a power of two near alpha / beta (x ~ beta / Gamma(alpha))
-  static M355_HD bool tab_ok(const K& k) { return k.alpha >= 1.0 && k.alpha <= 1e4 && k.beta > 0.0 && k.beta < kInf; }
-  static M355_DEV double tab_w(double x, const K& k) { return flog_tab_or_nan(x * pow2_near_inv(k.beta / k.alpha)); }
-  static M355_DEV double tab_x(double w, const K& k) { return fdiv(exp_(w), pow2_near_inv(k.beta / k.alpha)); }
+  // (shapes in [0.05, 1): the asinh-warped variable and tables of log(ppf), as for gamma -- here it is the upper tail
+  // that is the power law; below 0.05 ppf(1 - 1e-9) overflows)
+  static M355_HD bool tab_ok(const K& k) { return k.alpha >= 0.05 && k.alpha <= 1e4 && k.beta > 0.0 && k.beta < kInf; }
+  static M355_HD bool tab_ppf_log(const K& k) { return k.alpha < 1.0; }
+  static M355_DEV double tab_w(double x, const K& k) {
+    return tab_warp_if(k.alpha < 1.0, flog_tab_or_nan(x * pow2_near_inv(k.beta / k.alpha)));
+  }
+  static M355_DEV double tab_x(double w, const K& k) {
+    return fdiv(exp_(k.alpha < 1.0 ? tab_unwarp(w) : w), pow2_near_inv(k.beta / k.alpha));
+  }
   // sum of logpdf with the logarithms carried as a product (m355_math.h LogProd; protocol of Dist<M355_GAMMA>::SumAcc)
   struct SumAcc {
     LogProd px;
@@ -663,9 +670,12 @@ template <> struct Dist<M355_CHISQUARED> {
     return cdf_bounds(gammainc_p(k.h, x / 2.0, k.lgh), x, 0.0, kInf);
   }
   // k_tab (m355_elemwise.h; the conditions are Dist<M355_GAMMA>'s with alpha = nu / 2)
-  static M355_HD bool tab_ok(const K& k) { return k.nu >= 2.0 && k.nu <= 2e4; }
-  static M355_DEV double tab_w(double x, const K& k) { return flog_tab_or_nan(x * pow2_near_inv(k.nu)); }
-  static M355_DEV double tab_x(double w, const K& k) { return fdiv(exp_(w), pow2_near_inv(k.nu)); }
+  static M355_HD bool tab_ok(const K& k) { return k.nu >= 0.02 && k.nu <= 2e4; }
+  static constexpr bool kTabOkFn = true;
+  template <int FN> static M355_HD bool tab_ok_fn(const K& k) { return (FN != M355_PPF && FN != M355_ISF) || k.nu >= 0.1; }
+  static M355_HD bool tab_ppf_log(const K& k) { return k.nu < 2.0; }
+  static M355_DEV double tab_w(double x, const K& k) { return tab_warp_if(k.nu < 2.0, flog_tab_or_nan(x * pow2_near_inv(k.nu))); }
+  static M355_DEV double tab_x(double w, const K& k) { return fdiv(exp_(k.nu < 2.0 ? tab_unwarp(w) : w), pow2_near_inv(k.nu)); }
   // sum of logpdf with the logarithms carried as a product (m355_math.h LogProd; protocol of Dist<M355_GAMMA>::SumAcc)
   struct SumAcc {
     LogProd px;
@@ -722,9 +732,10 @@ template <> struct Dist<M355_SCALEDINVERSECHISQUARED> {
     return (x <= 0.0) ? 0.0 : flog(gammainc_p(k.h, k.ht / x, k.lgh));
   }
   // k_tab: log x, scaled by a power of two near 1 / tau2
-  static M355_HD bool tab_ok(const K& k) { return k.nu >= 2.0 && k.nu <= 2e4 && k.tau2 > 0.0 && k.tau2 < kInf; }
-  static M355_DEV double tab_w(double x, const K& k) { return flog_tab_or_nan(x * pow2_near_inv(k.tau2)); }
-  static M355_DEV double tab_x(double w, const K& k) { return fdiv(exp_(w), pow2_near_inv(k.tau2)); }
+  static M355_HD bool tab_ok(const K& k) { return k.nu >= 0.1 && k.nu <= 2e4 && k.tau2 > 0.0 && k.tau2 < kInf; }
+  static M355_HD bool tab_ppf_log(const K& k) { return k.nu < 2.0; }
+  static M355_DEV double tab_w(double x, const K& k) { return tab_warp_if(k.nu < 2.0, flog_tab_or_nan(x * pow2_near_inv(k.tau2))); }
+  static M355_DEV double tab_x(double w, const K& k) { return fdiv(exp_(k.nu < 2.0 ? tab_unwarp(w) : w), pow2_near_inv(k.tau2)); }
   // sum of logpdf with the logarithms carried as a product (m355_math.h LogProd; protocol of Dist<M355_GAMMA>::SumAcc)
   struct SumAcc {
     LogProd px;

@@ -515,7 +515,9 @@ def test_tabulated_kernel(gpu, name, params):
 
 @pytest.mark.parametrize("name, params", [("chisquared", (7.0,)), ("chisquared", (300.0,)), ("inversegamma", (3.0, 2.0)),
                                           ("inversegamma", (40.0, 1e3)), ("scaledinversechisquared", (5.0, 0.7)),
-                                          ("betascaled", (2.0, 5.0, -1.0, 3.0)), ("betascaled", (30.0, 1.5, 10.0, 10.5))])
+                                          ("betascaled", (2.0, 5.0, -1.0, 3.0)), ("betascaled", (30.0, 1.5, 10.0, 10.5)),
+                                          ("chisquared", (0.6,)), ("inversegamma", (0.3, 2.0)),
+                                          ("scaledinversechisquared", (0.7, 1.5))])
 def test_tabulated_kernel_relatives(gpu, name, params):
     """k_tab for the families of m355_dists2.h that share gamma's and beta's table variables (chisquared, inversegamma,
     scaledinversechisquared: log of the scaled argument; betascaled: logit of the standardised one): all six functions
@@ -560,7 +562,10 @@ def test_tabulated_kernel_relatives(gpu, name, params):
         assert np.array_equal(tab[sp_], exact[sp_], equal_nan=True), (fn, tab[sp_], exact[sp_])
         fin = np.isfinite(exact)
         if quant:
-            assert np.all(np.abs(tab[fin] - exact[fin]) <= 2e-13 * np.maximum(np.abs(exact[fin]), 1e-300) + 1e-13 * (hi - lo if np.isfinite(hi) else 0.0)), fn
+            with np.errstate(all="ignore"):  # (tables of log(ppf) for shapes below 1: relative error ~1e-14 max(1, |log x|))
+                lg = np.where(exact[fin] > 0, np.abs(np.log(np.where(exact[fin] > 0, exact[fin], 1.0))), 0.0)
+            assert np.all(np.abs(tab[fin] - exact[fin]) <= (2e-13 + 3e-14 * lg) * np.maximum(np.abs(exact[fin]), 1e-300)
+                          + 1e-13 * (hi - lo if np.isfinite(hi) else 0.0)), fn
             ok = H.ppf_close(name, fn, params, tab, exp) | H.ppf_unpinned(name, fn, arg) | ~np.isfinite(exp) | (tab == exact)
         else:
             assert np.all(np.abs(tab[fin] - exact[fin]) <= 5e-13 * np.maximum(1.0, np.abs(exact[fin]))), fn
@@ -764,9 +769,9 @@ def test_coltab_kernel(gpu, name, fn, P):
         params[0][:3] = [0.004, 3e4, 0.03 if quant else 0.001]
         draw = lambda: rng.gamma(params[0], 1.0 / params[1], (rows + 1, P))
         special = [nan, inf, -inf, 0.0, -1.0, 5e-324, 1e300]
-    elif name == "inversegamma":  # (m355_dists2.h: tables for alpha in [1, 1e4])
+    elif name == "inversegamma":  # (m355_dists2.h: tables for alpha in [0.05, 1e4])
         params = (rng.uniform(1.0, 30.0, P), rng.uniform(0.2, 5.0, P))
-        params[0][:3] = [0.5, 3e4, 0.9]
+        params[0][:3] = [0.02, 3e4, 0.04]
         draw = lambda: params[1] / rng.gamma(params[0], 1.0, (rows + 1, P))
         special = [nan, inf, -inf, 0.0, -1.0, 5e-324, 1e300]
     elif name == "beta":

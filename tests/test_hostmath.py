@@ -603,7 +603,8 @@ def test_host_lgamma1p_obs(hostlib):
     ("beta", (2.0, 3.0), 0), ("beta", (0.3, 4.0), 0), ("beta", (3.0, 0.2), 0), ("beta", (0.5, 0.5), 0),
     ("beta", (0.02, 0.05), 0), ("beta", (50.0, 0.5), 0), ("beta", (200.0, 1.5), 0),
     ("studentt", (3.0, 0.5, 2.0), 2), ("chisquared", (7.0,), 0), ("inversegamma", (3.0, 2.0), 0),
-    ("halfstudentt", (5.0, 2.0), 0), ("halfstudentt", (1.0, 0.3), 0), ("halfstudentt", (50.0, 1.0), 0),
+    ("chisquared", (0.6,), 0), ("chisquared", (0.05,), 0), ("inversegamma", (0.3, 2.0), 0), ("inversegamma", (0.05, 1.0), 0),
+    ("scaledinversechisquared", (0.7, 1.5), 0), ("halfstudentt", (5.0, 2.0), 0), ("halfstudentt", (1.0, 0.3), 0), ("halfstudentt", (50.0, 1.0), 0),
 ])
 def test_host_tab_build(hostlib, name, params, max_bad):
     """k_tab's table build (m355_elemwise.h) restated on the host (hm_tab_build): with the range ends, the warped
