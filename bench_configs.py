@@ -24,6 +24,30 @@ def timed(torch, fn, reps=5, warmup=1):
     return ts[len(ts) // 2]
 
 
+def spot_check(name, fn, src, out, params, stride=97, cols=None):
+    """After a timed region (never inside one): every `stride`-th element of `out` against the CPU oracle at the parity
+    bar of the tests (tests/harness.py: 1e-12 max(1, |b|), the modelled window for studentt quantiles).  `cols` = P for
+    row-periodic parameters of shape (P,).  Returns the worst scaled error; raises on a miss."""
+    import numpy as np
+
+    from oracle import restatement as R
+    from tests import harness as H
+
+    pts = src.view(-1)[::stride].cpu().numpy()
+    got = out.view(-1)[::stride].cpu().numpy()
+    if cols:
+        col = (np.arange(pts.size, dtype=np.int64) * stride) % cols
+        params = tuple(p.cpu().numpy()[col] if hasattr(p, "cpu") else p for p in params)
+    with np.errstate(all="ignore"):
+        exp = R.TABLE[f"{name}_{fn}"](pts, *params)
+        ok = H.ppf_close(name, fn, params, got, exp) | H.ppf_unpinned(name, fn, pts)
+        err = np.abs(got - exp) / np.maximum(1.0, np.abs(exp))
+    if not np.all(ok):
+        raise SystemExit(f"parity spot-check failed: {name}.{fn} {int((~ok).sum())} of {ok.size} points, e.g. x={pts[~ok][:3]} "
+                         f"got={got[~ok][:3]} oracle={exp[~ok][:3]}")
+    return float(np.nanmax(np.where(np.isfinite(err), err, 0.0))), int(ok.size)
+
+
 def config2(torch, n):
     """Gamma/Beta/StudentT(/Normal) logpdf+logcdf+logsf+ppf on n fp64 points, scalar params, plus
     the period-1024 broadcast-parameter layout for logpdf."""
@@ -36,13 +60,16 @@ def config2(torch, n):
     raw.rvs_into("uniform", (0.0, 1.0), q, seed=5)
     q.clamp_(1e-12, 1 - 1e-12)
     out = torch.empty(n, dtype=torch.float64, device=dev)
+    ews = raw.elemwise_workspace(dev)  # the launch-time tables of logcdf / logsf / ppf live here (m355_elemwise_ws)
     params = {"normal": (0.3, 1.7), "gamma": (2.5, 1.3), "beta": (2.0, 5.0), "studentt": (5.0, 0.0, 2.0)}
     for name, p in params.items():
         for fn in ("logpdf", "logcdf", "logsf", "ppf"):
             src = q if fn == "ppf" else xs[name]
-            ms = timed(torch, lambda: raw.elemwise_into(name, fn, src, p, out), reps=3 if fn == "ppf" else 5)
+            ms = timed(torch, lambda: raw.elemwise_into(name, fn, src, p, out, ews), reps=3 if fn == "ppf" else 5)
+            err, npts = spot_check(name, fn, src, out, p)
             print(json.dumps({"config": 2, "fn": f"{name}.{fn}", "n": n, "layout": "scalar params", "ms": ms,
-                              "evals_per_s": n / (ms * 1e-3), "GB_per_s_algorithmic": 16.0 * n / (ms * 1e-3) / 1e9}),
+                              "evals_per_s": n / (ms * 1e-3), "GB_per_s_algorithmic": 16.0 * n / (ms * 1e-3) / 1e9,
+                              "parity_points": npts, "parity_max_err": err}),
                   flush=True)
     # float32 in, float32 out (8 B per element; the arithmetic stays fp64, tolerance 1e-5)
     out32 = torch.empty(n, dtype=torch.float32, device=dev)
@@ -95,10 +122,12 @@ def periodic_special(torch, xs, q, out, rows):
             else:
                 ops[j].ptr, ops[j].scalar, ops[j].div, ops[j].mod, ops[j].dtype = p.data_ptr(), 0.0, 1, P, F64
         at = lambda k: ctypes.cast(ctypes.byref(ops, k * ctypes.sizeof(Operand)), ctypes.POINTER(Operand))
-        _lib.check(L.m355_elemwise(DIST[name], FN[fn], F64, n, at(0), len(params), at(1), out.data_ptr(), stream))
+        _lib.check(L.m355_elemwise_ws(DIST[name], FN[fn], F64, n, at(0), len(params), at(1), out.data_ptr(), ews.data_ptr(),
+                                      ews.numel(), stream))
 
     sums = torch.zeros(1, dtype=torch.float64, device=dev)
     ws = torch.empty(int(L.m355_sumlogp_workspace_bytes()), dtype=torch.uint8, device=dev)
+    ews = torch.empty(int(L.m355_elemwise_workspace_bytes()), dtype=torch.uint8, device=dev)  # the per-column tables
 
     def call_sum(name, params):
         ops = (Operand * (1 + len(params)))()
@@ -120,8 +149,10 @@ def periodic_special(torch, xs, q, out, rows):
         for fn in ("logpdf", "logcdf", "ppf"):
             src = q if fn == "ppf" else xs[name]
             ms = timed(torch, lambda: call(name, fn, src, params), reps=3)
+            err, npts = spot_check(name, fn, src[:n], out[:n], params, cols=P)
             print(json.dumps({"config": 2, "fn": f"{name}.{fn}", "n": n, "layout": "params (1024,) row-periodic", "ms": ms,
-                              "evals_per_s": n / (ms * 1e-3), "GB_per_s_algorithmic": 16.0 * n / (ms * 1e-3) / 1e9}), flush=True)
+                              "evals_per_s": n / (ms * 1e-3), "GB_per_s_algorithmic": 16.0 * n / (ms * 1e-3) / 1e9,
+                              "parity_points": npts, "parity_max_err": err}), flush=True)
 
 
 def config3(torch, n):
@@ -174,7 +205,17 @@ def config4(torch, n):
     ms = timed(torch, lambda: mvnormal.logpdf(X, mu_t, cov_t), reps=10, warmup=2)
     nbytes = 8.0 * (n * d + n + d * d + d)
     flops = n * (d * d + 3 * d) + d**3 / 3
+    # parity after the timed region: every 97th observation against the oracle (scipy.linalg restatement of
+    # mvnormal.py:17-37, 80-83) at 1e-12 max(1, |b|)
+    from oracle import restatement as R
+
+    got = mvnormal.logpdf(X, mu_t, cov_t)[::97].cpu().numpy()
+    exp = R.mvnormal_logpdf(X[::97].cpu().numpy(), mu, cov)
+    err_a = float(np.max(np.abs(got - exp) / np.maximum(1.0, np.abs(exp))))
+    if not err_a <= 1e-12:
+        raise SystemExit(f"parity spot-check failed: mvnormal.logpdf variant A, max scaled error {err_a}")
     print(json.dumps({"config": 4, "variant": "A (shared covariance)", "fn": "mvnormal.logpdf", "n": n, "d": d, "ms": ms,
+                      "parity_points": int(got.size), "parity_max_err": err_a,
                       "obs_per_s": n / (ms * 1e-3), "GB_per_s_algorithmic": nbytes / (ms * 1e-3) / 1e9,
                       "frac_hbm_peak": nbytes / (ms * 1e-3) / 8e12, "GFLOP_per_s": flops / (ms * 1e-3) / 1e9,
                       "frac_fp64_mfma_peak": flops / (ms * 1e-3) / 78.6e12,
@@ -196,12 +237,18 @@ def config4(torch, n):
     covb = torch.baddbmm(torch.eye(d, dtype=torch.float64, device=dev).expand(n, d, d), Ab, Ab.transpose(1, 2), alpha=1.0 / d)
     del Ab
     ms = timed(torch, lambda: mvnormal.logpdf(X, mu_t, covb), reps=5, warmup=1)
+    sel = slice(0, n, 97 * 8)  # (the oracle factors one matrix per point in a Python loop)
+    got = mvnormal.logpdf(X, mu_t, covb)[sel].cpu().numpy()
+    exp = np.array([float(R.mvnormal_logpdf(xr[None, :], mu, cv)[0]) for xr, cv in zip(X[sel].cpu().numpy(), covb[sel].cpu().numpy())])
+    err_b = float(np.max(np.abs(got - exp) / np.maximum(1.0, np.abs(exp))))
+    if not err_b <= 1e-12:
+        raise SystemExit(f"parity spot-check failed: mvnormal.logpdf variant B, max scaled error {err_b}")
     nbytes = 8.0 * n * (d * (d + 1) / 2 + 2 * d + 1)
     flops = n * (d**3 / 3 + d * d + 3 * d)
     print(json.dumps({"config": 4, "variant": "B (one covariance per observation)", "fn": "mvnormal.logpdf", "n": n, "d": d,
                       "ms": ms, "obs_per_s": n / (ms * 1e-3), "GB_per_s_algorithmic": nbytes / (ms * 1e-3) / 1e9,
                       "frac_hbm_peak": nbytes / (ms * 1e-3) / 8e12, "GFLOP_per_s": flops / (ms * 1e-3) / 1e9,
-                      "frac_fp64_mfma_peak": flops / (ms * 1e-3) / 78.6e12,
+                      "frac_fp64_mfma_peak": flops / (ms * 1e-3) / 78.6e12, "parity_points": int(got.size), "parity_max_err": err_b,
                       "note": "whole call; algorithmic bytes count the lower triangle of each covariance (SURVEY.md 8(d)): "
                               "1.77 GB at n = 1e5; the full matrices are 3.28 GB"}), flush=True)
 
@@ -220,6 +267,7 @@ def config6(torch, n):
              "halfstudentt": (5.0, 2.0), "betascaled": (2.0, 5.0, -1.0, 3.0)}
     dev = torch.device("cuda", 0)
     out = torch.empty(n, dtype=torch.float64, device=dev)
+    ews = raw.elemwise_workspace(dev)
     g = torch.Generator(device=dev).manual_seed(9)
     q = torch.rand(n, dtype=torch.float64, device=dev, generator=g).clamp_(1e-12, 1 - 1e-12)
     for name, p in cases.items():
@@ -228,7 +276,7 @@ def config6(torch, n):
         row = {"config": 6, "dist": name, "n": n}
         for fn in ("logpdf", "logcdf", "ppf"):
             src = q if fn == "ppf" else x
-            ms = timed(torch, lambda: raw.elemwise_into(name, fn, src, p, out), reps=3)
+            ms = timed(torch, lambda: raw.elemwise_into(name, fn, src, p, out, ews), reps=3)
             row[f"{fn}_ms"] = round(ms, 4)
             row[f"{fn}_GB_per_s"] = round(16.0 * n / (ms * 1e-3) / 1e9, 1)
         print(json.dumps(row), flush=True)

@@ -150,6 +150,32 @@ def _build_operands(pl: Plan, args: Sequence[Any], torch, device):
     return ops, keep
 
 
+# families whose logcdf / logsf / cdf / sf / ppf / isf the library can serve from launch-time tables, given a workspace
+# (include/m355_dist.h, m355_elemwise_ws): 20 KiB for scalar parameters; 9.2 KiB per column + one bit per element for
+# row-periodic ones
+TABLE_DISTS = ("gamma", "beta", "studentt", "halfstudentt", "chisquared", "inversegamma", "scaledinversechisquared",
+               "betascaled")
+_TABLE_WS_MAX = 1 << 30
+
+
+def _table_workspace(dist: str, fn: str, pl: Plan, torch, device):
+    """Scratch for m355_elemwise_ws, from torch's caching allocator (a per-call block: calls on different streams never
+    share one), or None where no table can apply."""
+    if dist not in TABLE_DISTS or fn in ("logpdf", "pdf") or pl.operands[0].kind != "full":
+        return None
+    period = 0
+    for op in pl.operands[1:]:
+        if op.kind == "scalar":
+            continue
+        if op.div != 1 or (period and op.mod != period):
+            return None  # not row-periodic: the library's generic kernel
+        period = int(op.mod)
+    need = int(_lib.lib().m355_elemwise_workspace_bytes_for(pl.n, period))
+    if need == 0 or need > _TABLE_WS_MAX:
+        return None
+    return torch.empty(need, dtype=torch.uint8, device=device)
+
+
 def _wants_torch(args) -> bool:
     return any(_is_torch(a) for a in args)
 
@@ -170,12 +196,14 @@ def elemwise(dist: str, fn: str, x: Any, *params: Any):
         if pl.n:
             ops, keep = _build_operands(pl, args, torch, device)
             stream = torch.cuda.current_stream(device).cuda_stream
-            rc = L.m355_elemwise(DIST[dist], FN[fn], F32 if pl.out_f32 else F64, pl.n,
-                                 ctypes.byref(ops[0]), len(params),
-                                 ctypes.cast(ctypes.byref(ops, ctypes.sizeof(Operand)), ctypes.POINTER(Operand)),
-                                 out.data_ptr(), stream)
+            ws = _table_workspace(dist, fn, pl, torch, device)
+            rc = L.m355_elemwise_ws(DIST[dist], FN[fn], F32 if pl.out_f32 else F64, pl.n,
+                                    ctypes.byref(ops[0]), len(params),
+                                    ctypes.cast(ctypes.byref(ops, ctypes.sizeof(Operand)), ctypes.POINTER(Operand)),
+                                    out.data_ptr(), ws.data_ptr() if ws is not None else None,
+                                    ws.numel() if ws is not None else 0, stream)
             _lib.check(rc)
-            del keep
+            del keep, ws  # (torch's allocator is stream-ordered: the block is not handed out again before this launch ran)
     out = out.reshape(pl.shape)
     if _wants_torch(args):
         return out

@@ -102,6 +102,11 @@ def lib():
             f"{LIB_PATH} is missing: the HIP library has not been built "
             "(make -C distributions_amd/csrc).  There is no CPU fallback."
         )
+    # torch first: it brings its own copy of the HIP runtime, and the process must hold ONE runtime -- the library's
+    # launches and torch's buffers / streams have to belong to the same one (loading the library before torch bound it
+    # to /opt/rocm's copy: "no ROCm-capable device is detected" at the first launch on the GPU box)
+    import torch  # noqa: F401
+
     L = ctypes.CDLL(LIB_PATH)
     vp, i32, i64, sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_size_t
     op = ctypes.POINTER(Operand)
@@ -110,6 +115,11 @@ def lib():
     L.m355_device_count.restype = i32
     L.m355_elemwise.restype = i32
     L.m355_elemwise.argtypes = [i32, i32, i32, i64, op, i32, op, vp, vp]
+    L.m355_elemwise_workspace_bytes.restype = sz
+    L.m355_elemwise_workspace_bytes_for.restype = sz
+    L.m355_elemwise_workspace_bytes_for.argtypes = [i64, i64]
+    L.m355_elemwise_ws.restype = i32
+    L.m355_elemwise_ws.argtypes = [i32, i32, i32, i64, op, i32, op, vp, vp, sz, vp]
     L.m355_sumlogp_workspace_bytes.restype = sz
     L.m355_sumlogp.restype = i32
     L.m355_sumlogp.argtypes = [i32, i32, i64, op, i32, op, vp, vp, sz, vp]

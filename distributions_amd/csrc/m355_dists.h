@@ -13,6 +13,15 @@ namespace m355 {
 
 template <int D> struct Dist;
 
+// k_tab / k_coltab (m355_elemwise.h) look cdf / sf up through the table of the LOG function the reference composes them
+// from -- e.g. gamma.py:40-41 cdf = exp(logcdf), gamma.py:53-54 sf = 1 - cdf, beta.py:82-83 sf = exp(logsf) -- so that a
+// small probability keeps the relative accuracy of its logarithm (a table of the probability itself is validated at
+// 1e-14 absolute only).  Dist<>::tab_route<FN>() names the tabulated function and the epilogue, FN = M355_CDF / M355_SF.
+enum { kTabEpiNone = 0, kTabEpiExp = 1, kTabEpiOneMinusExp = 2 };
+struct TabRoute {
+  int fn, epi;
+};
+
 // ------------------------------------------------------------------------------- helper.py:29-54
 M355_DEV double ppf_bounds_cont(double v, double q, double lower, double upper) {
   double r = (q == 1.0) ? upper : v;
@@ -160,6 +169,10 @@ template <> struct Dist<M355_GAMMA> {
   static constexpr bool kTabOkFn = true;
   template <int FN> static M355_HD bool tab_ok_fn(const K& k) { return (FN != M355_PPF && FN != M355_ISF) || k.alpha >= 0.05; }
   static M355_HD bool tab_ppf_log(const K& k) { return k.alpha < 1.0; }  // (below 0.05, ppf(1e-9) underflows)
+  // gamma.py:40-41 cdf = exp(logcdf); gamma.py:53-54 sf = 1 - cdf
+  template <int FN> static constexpr TabRoute tab_route() {
+    return FN == M355_CDF ? TabRoute{M355_LOGCDF, kTabEpiExp} : TabRoute{M355_LOGCDF, kTabEpiOneMinusExp};
+  }
   // (x is scaled by a power of two near beta / alpha first, so that |w| stays of the order of the spread of log x: for
   // large alpha the function is steep in w -- d log P / dw ~ sqrt(alpha) -- and log x itself would carry |log x| ulps;
   // alpha < 1: warped, see tab_warp)
@@ -269,6 +282,10 @@ template <> struct Dist<M355_BETA> {
     return true;
   }
   static M355_HD bool tab_warped(const K& k) { return (k.a < 1.0) | (k.b < 1.0); }
+  // beta.py:66-67 cdf = exp(logcdf); beta.py:82-83 sf = exp(logsf)
+  template <int FN> static constexpr TabRoute tab_route() {
+    return FN == M355_CDF ? TabRoute{M355_LOGCDF, kTabEpiExp} : TabRoute{M355_LOGSF, kTabEpiExp};
+  }
   // (range ends when even ppf(1e-3) / ppf(1 - 1e-3) round to 0 / 1: the outermost doubles inside the support)
   static M355_HD bool tab_ppf_log(const K& k) { return k.a < 1.0; }
   static M355_HD double tab_cap(bool upper, const K&) { return upper ? 1.0 - 0x1p-53 : 0x1p-1000; }
@@ -415,6 +432,10 @@ template <> struct Dist<M355_STUDENTT> {
   // modelled rounding of the reference's sqrt(1/b - 1), tests/harness.py _student_window.)
   // (nu <= 50: the band grows like nu -- 3 % of the mass at nu = 300 -- and the quantile's nodes get noisy with it)
   static M355_HD bool tab_ok(const K& k) { return k.nu >= 1.0 && k.nu <= 50.0 && k.sigma > 0.0 && k.sigma < kInf && k.mu - k.mu == 0.0; }
+  // studentt.py:67-68 cdf = exp(logcdf); studentt.py:92-93 sf = exp(logsf)
+  template <int FN> static constexpr TabRoute tab_route() {
+    return FN == M355_CDF ? TabRoute{M355_LOGCDF, kTabEpiExp} : TabRoute{M355_LOGSF, kTabEpiExp};
+  }
   static M355_DEV double tab_w(double x, const K& k) {
     const double z = fdiv_t<1, true>(x - k.mu, k.sigma), a = __builtin_fabs(z);
     const double w = flog_tab_or_nan(a + sqrt_(__builtin_fma(a, a, 1.0)));

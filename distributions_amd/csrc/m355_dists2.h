@@ -609,6 +609,10 @@ template <> struct Dist<M355_INVERSEGAMMA> {
   // that is the power law; below 0.05 ppf(1 - 1e-9) overflows)
   static M355_HD bool tab_ok(const K& k) { return k.alpha >= 0.05 && k.alpha <= 1e4 && k.beta > 0.0 && k.beta < kInf; }
   static M355_HD bool tab_ppf_log(const K& k) { return k.alpha < 1.0; }
+  // inversegamma.py:48-49 cdf = Q(alpha, beta / x), whose logarithm is logcdf (72-73); inversegamma.py:64-65 sf = exp(logsf)
+  template <int FN> static constexpr TabRoute tab_route() {
+    return FN == M355_CDF ? TabRoute{M355_LOGCDF, kTabEpiExp} : TabRoute{M355_LOGSF, kTabEpiExp};
+  }
   static M355_DEV double tab_w(double x, const K& k) {
     return tab_warp_if(k.alpha < 1.0, flog_tab_or_nan(x * pow2_near_inv(k.beta / k.alpha)));
   }
@@ -674,6 +678,10 @@ template <> struct Dist<M355_CHISQUARED> {
   static constexpr bool kTabOkFn = true;
   template <int FN> static M355_HD bool tab_ok_fn(const K& k) { return (FN != M355_PPF && FN != M355_ISF) || k.nu >= 0.1; }
   static M355_HD bool tab_ppf_log(const K& k) { return k.nu < 2.0; }
+  // chisquared.py:40-41 cdf = P(nu/2, x/2) = exp(logcdf); chisquared.py:77-78 sf = 1 - cdf
+  template <int FN> static constexpr TabRoute tab_route() {
+    return FN == M355_CDF ? TabRoute{M355_LOGCDF, kTabEpiExp} : TabRoute{M355_LOGCDF, kTabEpiOneMinusExp};
+  }
   static M355_DEV double tab_w(double x, const K& k) { return tab_warp_if(k.nu < 2.0, flog_tab_or_nan(x * pow2_near_inv(k.nu))); }
   static M355_DEV double tab_x(double w, const K& k) { return fdiv(exp_(k.nu < 2.0 ? tab_unwarp(w) : w), pow2_near_inv(k.nu)); }
   // sum of logpdf with the logarithms carried as a product (m355_math.h LogProd; protocol of Dist<M355_GAMMA>::SumAcc)
@@ -734,6 +742,10 @@ template <> struct Dist<M355_SCALEDINVERSECHISQUARED> {
   // k_tab: log x, scaled by a power of two near 1 / tau2
   static M355_HD bool tab_ok(const K& k) { return k.nu >= 0.1 && k.nu <= 2e4 && k.tau2 > 0.0 && k.tau2 < kInf; }
   static M355_HD bool tab_ppf_log(const K& k) { return k.nu < 2.0; }
+  // scaledinversechisquared.py:43-45 cdf = Q(h, h tau2 / x), whose logarithm is logcdf (70-72); 62-63 sf = exp(logsf)
+  template <int FN> static constexpr TabRoute tab_route() {
+    return FN == M355_CDF ? TabRoute{M355_LOGCDF, kTabEpiExp} : TabRoute{M355_LOGSF, kTabEpiExp};
+  }
   static M355_DEV double tab_w(double x, const K& k) { return tab_warp_if(k.nu < 2.0, flog_tab_or_nan(x * pow2_near_inv(k.tau2))); }
   static M355_DEV double tab_x(double w, const K& k) { return fdiv(exp_(k.nu < 2.0 ? tab_unwarp(w) : w), pow2_near_inv(k.tau2)); }
   // sum of logpdf with the logarithms carried as a product (m355_math.h LogProd; protocol of Dist<M355_GAMMA>::SumAcc)
@@ -884,6 +896,10 @@ template <> struct Dist<M355_BETASCALED> {
   }
   // k_tab: logit of the position in (lower, upper), both differences formed from x directly (conditions as for beta)
   static M355_HD bool tab_ok(const K& k) { return k.a >= 1.0 && k.b >= 1.0 && k.a + k.b <= 500.0 && k.w > 0.0 && k.w < kInf; }
+  // betascaled.py:71-72 cdf = exp(logcdf); betascaled.py:88-89 sf = 1 - cdf
+  template <int FN> static constexpr TabRoute tab_route() {
+    return FN == M355_CDF ? TabRoute{M355_LOGCDF, kTabEpiExp} : TabRoute{M355_LOGCDF, kTabEpiOneMinusExp};
+  }
   static M355_DEV double tab_w(double x, const K& k) { return flog_tab_or_nan(fdiv_t<1, true>(x - k.lo, k.hi - x)); }
   static M355_DEV double tab_x(double w, const K& k) { return __builtin_fma(k.w, fdiv(1.0, 1.0 + exp_(-w)), k.lo); }
   // sum of logpdf: sum log(x - lo), sum log(hi - x) as LogProds (protocol of Dist<M355_GAMMA>::SumAcc)

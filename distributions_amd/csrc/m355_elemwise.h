@@ -21,6 +21,7 @@
 #include <hip/hip_runtime.h>
 
 #include "m355_dist_list.h"
+#include <atomic>
 #include <cstdlib>
 #include <type_traits>
 
@@ -50,6 +51,8 @@ struct LaunchArgs {
   int* nblocks_out;  // receives the number of partials written
   double* table = nullptr;      // reduce only: device scratch for a table of derived constants (k_periodic_prod), or null
   long long table_doubles = 0;  // its capacity
+  double* ews = nullptr;        // elementwise only: the caller's workspace for the launch-time tables (k_tab, k_coltab), or null
+  size_t ews_doubles = 0;       // its capacity
   hipStream_t stream;
 };
 
@@ -806,23 +809,30 @@ template <class T, int FN> constexpr bool bin_this() {
   return (m == 1 && FN != M355_LOGPDF && FN != M355_PDF) || (m == 2 && (FN == M355_PPF || FN == M355_ISF));
 }
 
-// ---- Per-launch tabulation (scalar parameters, large n) ---------------------------------------------------------------
-// With the parameters fixed, logcdf / logsf / cdf / sf are smooth functions of ONE variable, and the exact bodies cost
-// 400-800 operations per element behind divergent loops.  k_tab has every workgroup tabulate the function once --
-// kTabCells cells across [ppf(1e-9), ppf(1 - 1e-9)] in a variable w = Dist<>::tab_w(x) in which the function is tame
-// (log x for gamma, logit x for beta, asinh z for studentt), a degree-15 Chebyshev interpolant per cell from 16 exact
-// evaluations at its Chebyshev nodes (1024 evaluations per workgroup, four per thread) -- and then evaluates its
-// elements from LDS: the coefficients are converted to the monomial basis in the cell's t in [-1, 1) -- safe because a
-// validated cell's Chebyshev coefficients decay by >= 8.6x per degree, so each monomial coefficient is dominated by its
-// own Chebyshev term -- and a lookup is one table logarithm, the cell arithmetic, eight 16-byte LDS reads and a
-// degree-15 Horner chain.
-// Every cell is validated: its last two coefficients must be below 1e-14 of its scale (they measure both the
-// truncation and any noise in the node values, e.g. from a badly conditioned x(w)); a cell that fails is poisoned with
-// NaN.  An element whose table value is NaN -- poisoned cell, w outside the table, NaN input -- takes the exact body.
-// So the table can only replace the exact value where it has shown itself converged; the price of a miss is divergence.
-constexpr int kTabCells = 64, kTabN = 16, kTabStride = 18;
+// ---- Tabulation at launch (scalar parameters, large n): k_tab_build + k_tab ------------------------------------------------
+// With the parameters fixed, logcdf / logsf / cdf / sf / ppf / isf are smooth functions of ONE variable, and the exact
+// bodies cost 400-3000 operations per element behind divergent loops.  The function is tabulated ONCE per call, by a
+// launch of its own (k_tab_build: 64 wavefronts, four cells each), into a workspace the caller brings
+// (m355_elemwise_ws, include/m355_dist.h); the evaluation kernel copies the finished table (20 KiB) into LDS:
+//   * kTabCells = 256 cells across [ppf(1e-9), ppf(1 - 1e-9)] in a variable w = Dist<>::tab_w(x) in which the function is
+//     tame (log x for gamma, logit x for beta, asinh z for studentt; logit q for the quantiles);
+//   * per cell a Chebyshev interpolant from kTabNodes = 12 exact evaluations at the cell's Chebyshev nodes, of which the
+//     first kTabCoef = 10 coefficients are kept (degree 9): the two that are dropped MEASURE what the truncation loses --
+//     and any noise in the node values (a badly conditioned x(w), the exact body's own rounding at large parameters) --
+//     so a cell is used only if |c_10| + |c_11| <= 1e-14 of its scale; a cell that fails is poisoned with NaN;
+//   * the kept coefficients are converted to the monomial basis in the cell's t in [-1, 1) (safe: a validated cell's
+//     coefficients fall by >= 25x per degree), ten doubles = 80 bytes per cell: a lookup is one table logarithm, the cell
+//     arithmetic, FIVE 16-byte LDS reads and a degree-9 Horner chain.  (Round 2 built a 64 x degree-15 table in every
+//     workgroup: 1024 workgroups x 1024 exact evaluations = 60 us per launch, and eight 16-byte reads per element made the
+//     kernel LDS-bound.  The 80-byte cell stride spreads eight neighbouring cells over all the banks.)
+// An element whose lookup is NaN -- poisoned cell, w outside the table, NaN / out-of-support argument -- takes the exact
+// body.  So the table can only replace the exact value where it has shown itself converged; the price of a miss is
+// divergence.
+constexpr int kTabCells = 256, kTabNodes = 12, kTabCoef = 10, kTabStride = 10, kTabHdr = 8;
+constexpr int kTabDoubles = kTabHdr + kTabCells * kTabStride;  // header: [0] w_lo, [1] cells per unit of w (NaN: no table)
+constexpr int kTabBuildWaves = kTabCells / 4;                   // k_tab_build: one wavefront (= workgroup) per four cells
 constexpr double kTabTailQ = 1e-9;     // the table spans the quantiles [kTabTailQ, 1 - kTabTailQ]
-constexpr double kTabCoefTol = 1e-14;  // |c_14| + |c_15| <= kTabCoefTol * max(1, |c_0|)
+constexpr double kTabCoefTol = 1e-14;  // dropped (k_tab) / last two (k_coltab) coefficients <= kTabCoefTol * scale
 template <class T, class = void> struct has_tab_var : std::false_type {};
 template <class T> struct has_tab_var<T, std::void_t<decltype(&T::tab_w)>> : std::true_type {};
 // optional per-distribution node evaluators (smooth versions of bodies whose reference formula is a staircase somewhere)
@@ -858,17 +868,43 @@ template <class T, class = void> struct has_tab_cap : std::false_type {};
 template <class T> struct has_tab_cap<T, std::void_t<decltype(&T::tab_cap)>> : std::true_type {};
 template <class T, class = void> struct has_tab_fnode : std::false_type {};
 template <class T> struct has_tab_fnode<T, std::void_t<decltype(T::kTabNode)>> : std::true_type {};  // tab_node<FN>
+// cdf / sf through the table of a log function (Dist<>::tab_route, m355_dists.h): the function a (dist, fn) pair tabulates
+// and what the lookup does with the table value
+template <class T, class = void> struct has_tab_route : std::false_type {};
+template <class T> struct has_tab_route<T, std::void_t<decltype(T::template tab_route<M355_CDF>())>> : std::true_type {};
+template <class DD, int FN> constexpr TabRoute tab_route_of() {
+  if constexpr (has_tab_route<DD>::value && (FN == M355_CDF || FN == M355_SF)) return DD::template tab_route<FN>();
+  else return TabRoute{FN, kTabEpiNone};
+}
+template <int EPI> M355_DEV double tab_epilogue(double r) {  // (NaN, the mark of a miss, passes through)
+  if constexpr (EPI == kTabEpiExp) return exp_(r);
+  else if constexpr (EPI == kTabEpiOneMinusExp) return 1.0 - exp_(r);
+  else return r;
+}
 template <class DD, int FN> constexpr bool tab_this() {
   return has_tab_var<DD>::value && (FN == M355_LOGCDF || FN == M355_LOGSF || FN == M355_CDF || FN == M355_SF ||
                                     FN == M355_PPF || FN == M355_ISF);
 }
 // Quantiles are tabulated in w = logit(q) over q in [kTabTailQ, 1 - kTabTailQ]: ppf(sigmoid(w)) is analytic in the strip
-// |Im w| < pi, and 64 cells of 0.65 converge like 0.1^n.  A node with w > 0 cannot be computed as ppf(q): q = 1 - p
-// rounds where p = sigmoid(-w) does not, so it takes ppf(fl(1 - p)) as a start and two Newton steps on
-// logsf(x) = log p, which holds its relative accuracy in the tail.  isf(q) is the reference's ppf(1 - q) with the
-// rounded 1 - q (e.g. gamma.py:57-58), so it looks up qq = fl(1 - q) -- the same staircase as the exact kernel.
+// |Im w| < pi.  A node with w > 0 cannot be computed as ppf(q): q = 1 - p rounds where p = sigmoid(-w) does not, so it
+// takes ppf(fl(1 - p)) as a start and two Newton steps on logsf(x) = log p, which holds its relative accuracy in the
+// tail.  isf(q) is the reference's ppf(1 - q) with the rounded 1 - q (e.g. gamma.py:57-58), so it looks up
+// qq = fl(1 - q) -- the same staircase as the exact kernel.
 constexpr double kTabLogitMax = 20.723265835946928;  // logit(1 - 1e-9)
-// cos(pi a / 32), a = 0 .. 63: the Chebyshev nodes of a cell are the odd entries, cos(pi m (q + 1/2) / 16) = entry m (2q + 1) mod 64
+// cos(pi a / 24), a = 0 .. 47: the 12 Chebyshev nodes of a k_tab cell are the odd entries below 24, and
+// cos(pi m (2 q + 1) / 24) = entry m (2 q + 1) mod 48
+constexpr double kCos24[48] = {
+    0x1.0000000000000p+0, 0x1.fb9ea92ec689bp-1, 0x1.ee8dd4748bf15p-1, 0x1.d906bcf328d46p-1, 0x1.bb67ae8584caap-1,
+    0x1.963268b572492p-1, 0x1.6a09e667f3bcdp-1, 0x1.37af93f9513eap-1, 0x1.0000000000000p-1, 0x1.87de2a6aea963p-2,
+    0x1.0907dc1930690p-2, 0x1.0b5150f6da2d1p-3, 0.0, -0x1.0b5150f6da2d1p-3, -0x1.0907dc1930690p-2, -0x1.87de2a6aea963p-2,
+    -0x1.0000000000000p-1, -0x1.37af93f9513eap-1, -0x1.6a09e667f3bcdp-1, -0x1.963268b572492p-1, -0x1.bb67ae8584caap-1,
+    -0x1.d906bcf328d46p-1, -0x1.ee8dd4748bf15p-1, -0x1.fb9ea92ec689bp-1, -0x1.0000000000000p+0, -0x1.fb9ea92ec689bp-1,
+    -0x1.ee8dd4748bf15p-1, -0x1.d906bcf328d46p-1, -0x1.bb67ae8584caap-1, -0x1.963268b572492p-1, -0x1.6a09e667f3bcdp-1,
+    -0x1.37af93f9513eap-1, -0x1.0000000000000p-1, -0x1.87de2a6aea963p-2, -0x1.0907dc1930690p-2, -0x1.0b5150f6da2d1p-3,
+    0.0, 0x1.0b5150f6da2d1p-3, 0x1.0907dc1930690p-2, 0x1.87de2a6aea963p-2, 0x1.0000000000000p-1, 0x1.37af93f9513eap-1,
+    0x1.6a09e667f3bcdp-1, 0x1.963268b572492p-1, 0x1.bb67ae8584caap-1, 0x1.d906bcf328d46p-1, 0x1.ee8dd4748bf15p-1,
+    0x1.fb9ea92ec689bp-1};
+// cos(pi a / 32), a = 0 .. 63: the same for the 16-node cells of k_coltab
 constexpr double kCos32[64] = {
     0x1.0000000000000p+0, 0x1.fd88da3d12526p-1, 0x1.f6297cff75cb0p-1, 0x1.e9f4156c62ddap-1,
     0x1.d906bcf328d46p-1, 0x1.c38b2f180bdb1p-1, 0x1.a9b66290ea1a3p-1, 0x1.8bc806b151741p-1,
@@ -899,7 +935,7 @@ struct ChebMono16 {
 };
 constexpr ChebMono16 kChebMono16{};
 
-// the function k_tab / k_coltab tabulate, at table variable w
+// the function k_tab_build / k_coltab_build tabulate, at table variable w
 template <class DD, int FN> M355_DEV double tab_node_value(double w, const typename DD::K& k) {
   constexpr bool QDOM = FN == M355_PPF || FN == M355_ISF;
   double f;
@@ -945,87 +981,74 @@ template <int D, int FN> __device__ __noinline__ double tab_exact(double x, cons
   return Dist<D>::template eval<FN>(x, k);
 }
 
-template <int D, int FN, bool F64IO>
-__global__ __launch_bounds__(kBlock) void k_tab(const void* __restrict__ x, int xdt, void* __restrict__ out, int odt,
-                                                long long n, const typename Dist<D>::K k) {
+// One wavefront per four cells: lane = 16 * (cell in the group) + node; lanes 12 .. 15 of a cell repeat node 11.
+template <int D, int FN>
+__global__ __launch_bounds__(64) void k_tab_build(const typename Dist<D>::K k, double* __restrict__ table) {
   using DD = Dist<D>;
-  constexpr int IO = F64IO ? 1 : 0;
-  // cell stride 18 doubles = 144 B: with 128 B every cell would start in the same LDS bank and lanes in different cells
-  // would serialise
-  __shared__ __attribute__((aligned(16))) double coef[kTabCells * kTabStride];
-  __shared__ double cosv[64];
-  __shared__ double tm[kTabN * kTabN];
-  __shared__ int bad[kTabCells];
-  __shared__ double rng[2];
   constexpr bool QDOM = FN == M355_PPF || FN == M355_ISF;
+  constexpr TabRoute RT = tab_route_of<DD, FN>();  // cdf / sf: the table holds RT.fn, the lookup applies RT.epi
+  __shared__ double fv[64];
+  __shared__ double rng[2];
   log_table_init();  // tab_w may use flog_tab
-  if (threadIdx.x < 2) {
-    if constexpr (QDOM) {
-      rng[threadIdx.x] = threadIdx.x == 0 ? -kTabLogitMax : kTabLogitMax;
-    } else {
-      rng[threadIdx.x] = tab_range_end<DD>(threadIdx.x == 1, k);
-    }
+  const int lane = threadIdx.x, cl = lane >> 4, m = lane & 15;
+  if (lane < 2) {
+    if constexpr (QDOM) rng[lane] = lane == 0 ? -kTabLogitMax : kTabLogitMax;
+    else rng[lane] = tab_range_end<DD>(lane == 1, k);
   }
-  if (threadIdx.x < 64) cosv[threadIdx.x] = kCos32[threadIdx.x];
-  tm[threadIdx.x] = kChebMono16.t[threadIdx.x >> 4][threadIdx.x & 15];  // (kBlock == 256 entries)
   __syncthreads();
   const double wlo = rng[0], whi = rng[1];
   const double h = (whi - wlo) * (1.0 / kTabCells);
-  const double inv_h = (h > 0.0) ? 1.0 / h : kNaN;  // (an empty or NaN range poisons every lookup)
-  // node values: thread t takes (cell, node) = (j >> 4, j & 15) for j = t, t + 256, ...
-  for (int j = threadIdx.x; j < kTabCells * kTabN; j += kBlock) {
-    const double w = wlo + h * ((double)(j >> 4) + 0.5 + 0.5 * cosv[2 * (j & 15) + 1]);
-    const double f = tab_node_value<DD, FN>(w, k);
-    coef[(j >> 4) * kTabStride + (j & 15)] = f;
-  }
+  const int cell = blockIdx.x * 4 + cl;
+  const int jn = m < kTabNodes ? m : kTabNodes - 1;
+  const double w = wlo + h * ((double)cell + 0.5 + 0.5 * kCos24[2 * jn + 1]);
+  fv[lane] = (h > 0.0) ? tab_node_value<DD, RT.fn>(w, k) : kNaN;  // (an empty or NaN range: no table, see the header)
   __syncthreads();
-  // Chebyshev coefficients of each cell: c_m = (2 / 16) sum_j f_j cos(pi m (j + 1/2) / 16), c_0 halved
-  double cm[kTabCells * kTabN / kBlock];
-#pragma unroll
-  for (int r = 0; r < kTabCells * kTabN / kBlock; ++r) {
-    const int j = threadIdx.x + r * kBlock, cell = j >> 4, m = j & 15;
+  // Chebyshev coefficients: c_m = (2 / 12) sum_j f_j cos(pi m (j + 1/2) / 12), c_0 halved
+  double c = 0.0;
+  if (m < kTabNodes) {
     double acc = 0.0;
 #pragma unroll
-    for (int q = 0; q < kTabN; ++q) {
-      acc = __builtin_fma(coef[cell * kTabStride + q], cosv[(m * (2 * q + 1)) & 63], acc);
-    }
-    cm[r] = acc * (m == 0 ? 1.0 / 16.0 : 2.0 / 16.0);
+    for (int q = 0; q < kTabNodes; ++q) acc = __builtin_fma(fv[cl * 16 + q], kCos24[(m * (2 * q + 1)) % 48], acc);
+    c = acc * (m == 0 ? 1.0 / kTabNodes : 2.0 / kTabNodes);
   }
+  // the parity bar is relative to max(1, |value|); a quantile must hold it relative to the root itself (sum |c_k| >= the
+  // cell's sup norm; |c_0| alone would vanish where a quantile changes sign); log mode: an absolute error e of the table
+  // is a relative error e of the quantile: scale max(1, |log x|)
+  double sum = __builtin_fabs(c), tail = (m >= kTabCoef) ? __builtin_fabs(c) : 0.0;
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) {
+    sum += __shfl_xor(sum, o, 16);
+    tail += __shfl_xor(tail, o, 16);
+  }
+  const double scale = ((QDOM && !tab_log_mode<DD, FN>(k)) || sum > 1.0) ? sum : 1.0;
+  const bool bad = !(tail <= kTabCoefTol * scale);  // NaN / inf coefficients are bad too
   __syncthreads();
-#pragma unroll
-  for (int r = 0; r < kTabCells * kTabN / kBlock; ++r) {
-    const int j = threadIdx.x + r * kBlock;
-    coef[(j >> 4) * kTabStride + (j & 15)] = cm[r];
-  }
+  fv[lane] = c;
   __syncthreads();
-  if (threadIdx.x < kTabCells) {
-    const double* c = coef + threadIdx.x * kTabStride;
-    // the parity bar is relative to max(1, |value|); a quantile must hold it relative to the root itself
-    // (sum |c_k| >= the cell's sup norm; |c_0| alone would vanish where a quantile changes sign)
-    double sum = 0.0;
-#pragma unroll
-    for (int q = 0; q < kTabN; ++q) sum += __builtin_fabs(c[q]);
-    // (log mode: an absolute error e of the table is a relative error e of the quantile: scale max(1, |log x|))
-    const double scale = ((QDOM && !tab_log_mode<DD, FN>(k)) || sum > 1.0) ? sum : 1.0;
-    const double tail = __builtin_fabs(c[14]) + __builtin_fabs(c[15]);
-    bad[threadIdx.x] = !(tail <= kTabCoefTol * scale);  // NaN / inf coefficients are bad too
-  }
-  // monomial coefficients a_j = sum_k c_k T_k[j]
-#pragma unroll
-  for (int r = 0; r < kTabCells * kTabN / kBlock; ++r) {
-    const int j = threadIdx.x + r * kBlock, cell = j >> 4, m = j & 15;
+  if (m < kTabCoef) {  // monomial coefficients a_m = sum_{k < 10} c_k T_k[m]
     double acc = 0.0;
 #pragma unroll
-    for (int q = 0; q < kTabN; ++q) acc = __builtin_fma(coef[cell * kTabStride + q], tm[q * kTabN + m], acc);
-    cm[r] = acc;
+    for (int q = 0; q < kTabCoef; ++q) acc = __builtin_fma(fv[cl * 16 + q], kChebMono16.t[q][m], acc);
+    table[kTabHdr + cell * kTabStride + m] = (m == 0 && bad) ? kNaN : acc;
   }
-  __syncthreads();
-#pragma unroll
-  for (int r = 0; r < kTabCells * kTabN / kBlock; ++r) {
-    const int j = threadIdx.x + r * kBlock;
-    coef[(j >> 4) * kTabStride + (j & 15)] = ((j & 15) == 0 && bad[j >> 4]) ? kNaN : cm[r];
+  if (blockIdx.x == 0 && lane == 0) {
+    table[0] = wlo;
+    table[1] = (h > 0.0) ? 1.0 / h : kNaN;  // (NaN poisons every lookup)
   }
-  __syncthreads();
+}
+
+template <int D, int FN, bool F64IO>
+__global__ __launch_bounds__(kBlock) void k_tab(const void* __restrict__ x, int xdt, void* __restrict__ out, int odt,
+                                                long long n, const typename Dist<D>::K k, const double* __restrict__ table) {
+  using DD = Dist<D>;
+  constexpr int IO = F64IO ? 1 : 0;
+  constexpr bool QDOM = FN == M355_PPF || FN == M355_ISF;
+  constexpr TabRoute RT = tab_route_of<DD, FN>();
+  __shared__ __attribute__((aligned(16))) double tab[kTabDoubles];
+  for (int i = threadIdx.x; i < kTabDoubles; i += kBlock) tab[i] = table[i];
+  log_table_init();  // (its barrier publishes `tab` too)
+  const double wlo = tab[0], inv_h = tab[1];
+  const double* coef = tab + kTabHdr;
   // table value, NaN where the table has nothing to say (w outside it, a poisoned cell, a NaN argument)
   auto lookup = [&](double xv) -> double {
     double wv;
@@ -1041,15 +1064,16 @@ __global__ __launch_bounds__(kBlock) void k_tab(const void* __restrict__ x, int 
     const bool in = (s >= 0.0) & (s < (double)kTabCells);
     const double t = __builtin_fma(2.0, s - fi, -1.0);
     const d2_t* c = reinterpret_cast<const d2_t*>(coef + (in ? (int)fi : 0) * kTabStride);
-    d2_t cc = c[kTabN / 2 - 1];
+    d2_t cc = c[kTabCoef / 2 - 1];
     double r = __builtin_fma(cc.y, t, cc.x);
 #pragma unroll
-    for (int q = kTabN / 2 - 2; q >= 0; --q) {
+    for (int q = kTabCoef / 2 - 2; q >= 0; --q) {
       cc = c[q];  // a_{2q}, a_{2q+1}
       r = __builtin_fma(__builtin_fma(r, t, cc.y), t, cc.x);
     }
     if (tab_log_mode<DD, FN>(k)) r = exp_(r);  // (uniform)
-    if constexpr (has_tab_value_miss<DD>::value) r = DD::template tab_value_miss<FN>(r) ? kNaN : r;
+    if constexpr (has_tab_value_miss<DD>::value) r = DD::template tab_value_miss<RT.fn>(r) ? kNaN : r;
+    r = tab_epilogue<RT.epi>(r);
     return in ? r : kNaN;
   };
   const long long ntiles = n / kTile;
@@ -1097,311 +1121,315 @@ __global__ __launch_bounds__(kBlock) void k_tab(const void* __restrict__ x, int 
   }
 }
 
-// ---- The same tables for row-periodic parameters (x of shape (R, P), parameters of shape (P,)) ------------------------
-// A column of x shares one parameter set, so it can share one table.  A workgroup of 512 threads takes kCtCols = 16
-// adjacent columns (a row's 16 values are one 128-byte line) and a slice of the rows: it derives the 16 parameter sets,
-// builds their 16 tables (144 KiB of the CU's 160 KiB LDS, so one workgroup per CU; 16384 node evaluations, wave-uniform
-// parameters), and walks its rows with thread t on column t & 15 -- every thread keeps one table, one range and one
-// parameter set for the whole launch.  Validation, poisoning and misses as in k_tab; a column whose parameters
-// Dist<>::tab_ok declines gets an empty range, i.e. the exact body for all its elements.
-constexpr int kCtCols = 16, kCtBlock = 512, kCtRows = kCtBlock / kCtCols;
-// rows per thread and tile: eight for quantiles (the lookup needs no per-lane parameters), four for the cdf family (with
-// eight, the per-lane constants of tab_w on top of ~60 VGPRs per lookup in flight spill inside the loop)
-template <int FN> constexpr int ct_unroll() { return (FN == M355_PPF || FN == M355_ISF) ? 8 : 4; }
-constexpr int kCtTable = kTabCells * kTabStride;                      // doubles per table
-constexpr size_t kCtLds = (size_t)kCtCols * kCtTable * sizeof(double);  // dynamic LDS: 147456 B
+// ---- The same for row-periodic parameters (x of shape (R, P), parameters of shape (P,)): k_coltab_* ------------------------
+// A column of x shares one parameter set, so it can share one table.  All P tables are built once, by the whole grid, into
+// the caller's workspace, 64 cells x degree 11 per column (sixteen tables of that size fit a CU's LDS; k_tab's wider
+// format would not):
+//   k_coltab_ranges   one thread per (column, end): derive, Dist<>::tab_ok, the two quantile evaluations of the range;
+//   k_coltab_build    one lane per node (a wavefront = four cells of ONE column, so the exact bodies run with
+//                     wavefront-uniform parameters), 16-point DCT through LDS, validation, monomial basis;
+//   k_coltab          the lookups.  A workgroup of 1024 threads takes kCtCols = 16 adjacent columns (a row's 16 values are
+//                     one 128-byte line), their tables in LDS (115 KiB: one workgroup per CU, four wavefronts per SIMD),
+//                     thread t on column t & 15.  Rows are handed out in chunks of 4096 from a counter per column group; a
+//                     workgroup serves its home group until that is exhausted and then helps the others (reloading
+//                     tables), so groups with slower columns -- warped tables -- do not set the pace.  The kernel calls
+//                     nothing: a miss is not stored, it becomes one bit in the workspace (one 64-bit word per thread and
+//                     chunk).  With the exact bodies callable from it the kernel needed 248 VGPRs, two wavefronts per
+//                     SIMD, and ran at 0.7-1.0 ms per 1e8 elements with VALU and LDS both under 40 % busy;
+//   k_coltab_fix      scans the miss words and redoes those elements by the exact body -- from x, which the lookup kernel
+//                     left alone there, so out may be x itself;
+//   k_coltab_declined the columns whose parameters Dist<>::tab_ok declines (flag in the column's table header).
+// Round 2 gave each of 256 workgroups 16 columns = 16384 exact evaluations before its first row.
+// per-column table: 64 cells x 16 nodes of which the first 12 coefficients are kept (degree 11; the four that are dropped
+// measure the truncation, as in k_tab_build) -- six 16-byte reads per lookup instead of round 2's eight; 112-byte cells
+// (a stride of 28 banks spreads eight neighbouring cells over all of them)
+constexpr int kCtCells = 64, kCtN = 16, kCtCoef = 12, kCtStride = 14;
 constexpr int kCtMaxNK = 12;
+// header: [0] w_lo, [1] cells per unit of w, [2] declined, [3] log mode, [4] cell width, [8 ..) the column's derived constants
+constexpr int kCtHdr = 8 + kCtMaxNK + 4;
+constexpr int kCtTable = kCtHdr + kCtCells * kCtStride;              // 920 doubles per column
+constexpr int kCtCols = 16, kCtThreads = 1024, kCtRows = kCtThreads / kCtCols;  // workgroup: 16 columns x 64 rows per pass
+// rows per thread and pass (independent lookups in flight per lane): four for the quantiles (their lookup needs no
+// per-lane parameters: 71 - 128 VGPRs), two for the cdf family (with four, the per-lane constants of tab_w on top of the
+// sixteen coefficient registers of every lookup in flight spilled 76 - 188 bytes per lane under the 128-VGPR budget of a
+// 1024-thread workgroup)
+#ifndef M355_CT_UNROLL_CDF
+#define M355_CT_UNROLL_CDF 2
+#endif
+template <int FN> constexpr int ct_unroll() { return (FN == M355_PPF || FN == M355_ISF) ? 4 : M355_CT_UNROLL_CDF; }
+template <int FN> constexpr int ct_iters() { return 64 / ct_unroll<FN>(); }                    // passes per chunk: one miss bit per element
+template <int FN> constexpr int ct_chunk_rows() { return ct_iters<FN>() * ct_unroll<FN>() * kCtRows; }  // 4096
+constexpr size_t kCtLds = (size_t)kCtCols * kCtTable * sizeof(double);  // dynamic LDS: 117760 B
+// workspace: P tables | G chunk counters (+ padding to 8 bytes) | one miss word per (group, chunk, thread) = n / 64 words
+template <int FN> inline size_t coltab_chunks(long long R) { return (size_t)((R + ct_chunk_rows<FN>() - 1) / ct_chunk_rows<FN>()); }
+template <int FN> inline size_t coltab_ws_doubles(unsigned long long P, long long R) {
+  const size_t G = (size_t)(P / kCtCols);
+  return (size_t)P * kCtTable + (G + 2) / 2 + G * coltab_chunks<FN>(R) * kCtThreads;
+}
 
-// k_coltab's LDS, at namespace scope so that the row loop can live in a function of its own (coltab_rows) and still
-// address it as LDS
-extern __shared__ __attribute__((aligned(16))) double ct_coef[];  // [kCtCols][kTabCells][kTabStride]
-static __shared__ double ct_kt[kCtCols * kCtMaxNK];                // derived constants per column
-static __shared__ double ct_rng[2 * kCtCols];                      // table range per column
-static __shared__ int ct_logmode[kCtCols];                         // quantile table holds log(ppf) (tab_log_mode)
-static __shared__ int ct_declined[kCtCols];                        // Dist<>::tab_ok / tab_ok_fn said no: k_coltab_declined's column
 template <class DD, int FN> M355_DEV bool coltab_params_ok(const typename DD::K& k) {
   bool ok = DD::tab_ok(k);
   if constexpr (has_tab_ok_fn<DD>::value) ok = ok && DD::template tab_ok_fn<FN>(k);
   return ok;
 }
 
-// A thread's tile redone where the stored result is NaN (the mark of a miss; a NaN that the exact body itself returns
-// is simply recomputed).
+// thread 2 c + e: end e of column c's range; thread 2 c also writes the flags; the first G threads zero the chunk counters
 template <int D, int FN>
-__device__ __noinline__ void coltab_fixup(const void* x, int xdt, void* out, int odt, long long row0, long long R, long long P,
-                                          long long gcol, const double* kd) {
-  using K = typename Dist<D>::K;
-  constexpr int NK = sizeof(K) / sizeof(double);
-  K k;
-  double* dst = reinterpret_cast<double*>(&k);
-#pragma unroll
-  for (int f = 0; f < NK; ++f) dst[f] = kd[f];
-#pragma unroll 1
-  for (int u = 0; u < ct_unroll<FN>(); ++u) {
-    const long long row = row0 + u * kCtRows;
-    if (row < R) {
-      const long long idx = row * P + gcol;
-      const double o = load1(out, odt, (unsigned long long)idx);
-      if (o != o) store1(out, odt, idx, Dist<D>::template eval<FN>(load1(x, xdt, (unsigned long long)idx), k));
-    }
-  }
-}
-// (out of line: the build phase's heavy bodies must not shape the register allocation of the row loop)
-template <int D, int FN> __device__ __noinline__ double coltab_node(double w, const double* kd) {
-  using K = typename Dist<D>::K;
-  constexpr int NK = sizeof(K) / sizeof(double);
-  K k;
-  double* dst = reinterpret_cast<double*>(&k);
-#pragma unroll
-  for (int f = 0; f < NK; ++f) dst[f] = kd[f];
-  return tab_node_value<Dist<D>, FN>(w, k);
-}
-template <int D, int FN> __device__ __noinline__ double coltab_range_end(bool upper, const double* kd) {
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(min_waves<Dist<D>>::value))) void k_coltab_ranges(
+    PeriodicParams pa, unsigned P, double* __restrict__ ws, unsigned* __restrict__ counters, unsigned ncounters) {
   using DD = Dist<D>;
   using K = typename DD::K;
-  constexpr int NK = sizeof(K) / sizeof(double);
-  K k;
-  double* dst = reinterpret_cast<double*>(&k);
-#pragma unroll
-  for (int f = 0; f < NK; ++f) dst[f] = kd[f];
-  if (!coltab_params_ok<DD, FN>(k)) return kNaN;
-  if constexpr (FN == M355_PPF || FN == M355_ISF) return upper ? kTabLogitMax : -kTabLogitMax;
-  else return tab_range_end<DD>(upper, k);
-}
-
-// The row loop of k_coltab for one epoch (row blocks rbe, rbe + rbstep, ... at most 64 of them): looks every element up
-// in its column's table, stores the result (NaN where the table has nothing to say) and returns the set of row blocks in
-// which this thread met a NaN.
-template <int D, int FN, bool F64IO>
-__device__ __noinline__ unsigned long long coltab_rows(const void* __restrict__ x_, int xdt, void* __restrict__ out_, int odt,
-                                                       long long R, unsigned P, unsigned g, long long rbe, long long rbstep,
-                                                       long long row_blocks) {
-  using DD = Dist<D>;
-  using K = typename DD::K;
-  constexpr int NK = sizeof(K) / sizeof(double);
   constexpr bool QDOM = FN == M355_PPF || FN == M355_ISF;
-  const int t = threadIdx.x;
-  // (function arguments arrive in vector registers: tell the compiler which are wavefront-uniform, and that the data
-  // pointers are global memory)
-  R = uniform_ll(R);
-  P = (unsigned)__builtin_amdgcn_readfirstlane((int)P);
-  g = (unsigned)__builtin_amdgcn_readfirstlane((int)g);
-  rbe = uniform_ll(rbe);
-  rbstep = uniform_ll(rbstep);
-  row_blocks = uniform_ll(row_blocks);
-  xdt = __builtin_amdgcn_readfirstlane(xdt);
-  odt = __builtin_amdgcn_readfirstlane(odt);
-  const void* x = reinterpret_cast<const void*>(uniform_ll(reinterpret_cast<long long>(x_)));
-  void* out = reinterpret_cast<void*>(uniform_ll(reinterpret_cast<long long>(out_)));
-  // this thread's column
-  const int col = t & (kCtCols - 1), rloc = t >> 4;
-  const double* mycoef = ct_coef + col * kCtTable;
-  const double* myk = ct_kt + col * kCtMaxNK;
-  K k;
-  {
-    double* kd = reinterpret_cast<double*>(&k);
+  log_table_init();
+  const unsigned i = blockIdx.x * kBlock + threadIdx.x;
+  if (i < ncounters) counters[i] = 0u;
+  if (i >= 2 * P) return;
+  const unsigned col = i >> 1, e = i & 1;
+  double pp[kMaxParams];
 #pragma unroll
-    for (int f = 0; f < NK; ++f) kd[f] = myk[f];
+  for (int q = 0; q < kMaxParams; ++q) pp[q] = (q < DD::NP && pa.ptr[q]) ? pa.ptr[q][col] : pa.scalar[q];
+  const K k = DD::derive(pp);
+  const bool declined = !coltab_params_ok<DD, FN>(k);
+  double we = kNaN;
+  if (!declined) {
+    if constexpr (QDOM) we = e == 0 ? -kTabLogitMax : kTabLogitMax;
+    else we = tab_range_end<DD>(e == 1, k);
   }
-  const double wlo = ct_rng[2 * col], whi = ct_rng[2 * col + 1];
-  const double hh = (whi - wlo) * (1.0 / kTabCells);
-  const double inv_h = (hh > 0.0) ? 1.0 / hh : kNaN;
-  // no table for this column: k_coltab_declined does it, this loop leaves it alone.  (A column that was accepted but whose
-  // range came out empty -- not seen in practice -- has NaN lookups throughout: misses, redone by coltab_fixup.)
-  const bool declined = ct_declined[col] != 0;
-  const bool logmode = ct_logmode[col] != 0;
-  auto lookup = [&](double xv) -> double {
-    double wv;
-    if constexpr (QDOM) {
-      const double qq = (FN == M355_ISF) ? 1.0 - xv : xv;
-      wv = tab_logit<DD>(qq);
-      if constexpr (has_tab_node<DD>::value) wv = DD::tab_q_miss(qq) ? kNaN : wv;
-    } else {
-      wv = DD::tab_w(xv, k);
-    }
-    const double s_ = (wv - wlo) * inv_h;
-    const double fi = __builtin_floor(s_);
-    const bool in = (s_ >= 0.0) & (s_ < (double)kTabCells);
-    const double tt = __builtin_fma(2.0, s_ - fi, -1.0);
-    const d2_t* c = reinterpret_cast<const d2_t*>(mycoef + (in ? (int)fi : 0) * kTabStride);
-    d2_t cc = c[kTabN / 2 - 1];
-    double r = __builtin_fma(cc.y, tt, cc.x);
+  // the pair's two ends meet in lanes 2 c, 2 c + 1 of one wavefront
+  const double other = __shfl_xor(we, 1, 64);
+  if (e == 0) {
+    double* table = ws + (size_t)col * kCtTable;
+    const double h = (other - we) * (1.0 / kCtCells);
+    table[0] = we;
+    table[1] = (h > 0.0) ? 1.0 / h : kNaN;  // (an accepted column whose range came out empty: every lookup a miss)
+    table[2] = declined ? 1.0 : 0.0;
+    table[3] = tab_log_mode<DD, FN>(k) ? 1.0 : 0.0;
+    table[4] = h;
+    constexpr int NK = sizeof(K) / sizeof(double);
+    static_assert(NK <= kCtMaxNK, "k_coltab: K too large");
+    const double* kd = reinterpret_cast<const double*>(&k);
 #pragma unroll
-    for (int q = kTabN / 2 - 2; q >= 0; --q) {
-      cc = c[q];
-      r = __builtin_fma(__builtin_fma(r, tt, cc.y), tt, cc.x);
-    }
-    if constexpr (QDOM && has_tab_ppf_log<DD>::value) {
-      if (__builtin_amdgcn_ballot_w64(logmode) != 0) r = logmode ? exp_(r) : r;  // (skipped when no lane of the wavefront wants it)
-    }
-    if constexpr (has_tab_value_miss<DD>::value) r = DD::template tab_value_miss<FN>(r) ? kNaN : r;
-    return in ? r : kNaN;
-  };
-  constexpr int kCtUnroll = ct_unroll<FN>();
-  constexpr int kRowsPerIter = kCtRows * kCtUnroll;
-  // addresses as a wavefront-uniform base (scalar registers) plus one 32-bit per-lane offset: sixteen 64-bit per-lane
-  // addresses would cost 32 VGPRs
-  const unsigned lane_off = (unsigned)rloc * P + (unsigned)col;  // elements; rloc < 32
-  unsigned long long missed = 0;
-  int it = 0;
-  for (long long rb = rbe; rb < row_blocks && it < 64; rb += rbstep, ++it) {
-    const long long ubase = rb * kRowsPerIter * (long long)P + (long long)g * kCtCols;  // uniform
-    const long long rows_left = R - rb * kRowsPerIter;                                 // uniform
-    double v[kCtUnroll], r[kCtUnroll];
-#pragma unroll
-    for (int u = 0; u < kCtUnroll; ++u) {
-      const long long ub = ubase + (long long)(u * kCtRows) * (long long)P;
-      const bool live = (rloc < rows_left - u * kCtRows) & !declined;
-      if constexpr (F64IO) v[u] = live ? ((const gdouble*)x + ub)[lane_off] : kNaN;
-      else v[u] = live ? load1(x, xdt, (unsigned long long)(ub + lane_off)) : kNaN;
-    }
-    bool miss = false;
-#pragma unroll
-    for (int u = 0; u < kCtUnroll; ++u) {
-      r[u] = lookup(v[u]);
-      miss |= r[u] != r[u];
-    }
-#pragma unroll
-    for (int u = 0; u < kCtUnroll; ++u) {
-      const long long ub = ubase + (long long)(u * kCtRows) * (long long)P;
-      const bool live = (rloc < rows_left - u * kCtRows) & !declined;
-      if constexpr (F64IO) {
-        if (live) ((gdouble*)out + ub)[lane_off] = r[u];
-      } else {
-        if (live) store1(out, odt, ub + lane_off, r[u]);
-      }
-    }
-    if (miss & !declined) missed |= 1ull << it;
+    for (int f = 0; f < NK; ++f) table[8 + f] = kd[f];  // k_coltab reads them from LDS: it derives (and calls) nothing
   }
-  return missed;
 }
 
+// grid = 4 P workgroups of 256 threads: workgroup b builds cells 16 (b & 3) .. + 15 of column b >> 2 (wavefront = four cells)
+template <int D, int FN>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(min_waves<Dist<D>>::value))) void k_coltab_build(
+    PeriodicParams pa, unsigned P, double* __restrict__ ws) {
+  using DD = Dist<D>;
+  using K = typename DD::K;
+  constexpr bool QDOM = FN == M355_PPF || FN == M355_ISF;
+  constexpr TabRoute RT = tab_route_of<DD, FN>();
+  __shared__ double fv[kBlock];
+  const int t = threadIdx.x, m = t & 15;
+  const unsigned col = blockIdx.x >> 2;
+  const int cell = (int)(blockIdx.x & 3) * 16 + (t >> 4);
+  double* table = ws + (size_t)col * kCtTable;
+  if (table[2] != 0.0) return;  // (uniform over the workgroup) declined: k_coltab_declined's column
+  log_table_init();
+  double pp[kMaxParams];
+#pragma unroll
+  for (int q = 0; q < kMaxParams; ++q) pp[q] = (q < DD::NP && pa.ptr[q]) ? pa.ptr[q][col] : pa.scalar[q];
+  const K k = DD::derive(pp);  // (every thread: the same values)
+  const double wlo = table[0], h = table[4];
+  {
+    const double w = wlo + h * ((double)cell + 0.5 + 0.5 * kCos32[2 * m + 1]);
+    fv[t] = (h > 0.0) ? tab_node_value<DD, RT.fn>(w, k) : kNaN;
+  }
+  __syncthreads();
+  double c;
+  {
+    double acc = 0.0;
+#pragma unroll
+    for (int q = 0; q < kCtN; ++q) acc = __builtin_fma(fv[(t & ~15) + q], kCos32[(m * (2 * q + 1)) & 63], acc);
+    c = acc * (m == 0 ? 1.0 / kCtN : 2.0 / kCtN);
+  }
+  double sum = __builtin_fabs(c), tail = (m >= kCtCoef) ? __builtin_fabs(c) : 0.0;
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) {
+    sum += __shfl_xor(sum, o, 16);
+    tail += __shfl_xor(tail, o, 16);
+  }
+  const double scale = ((QDOM && !tab_log_mode<DD, FN>(k)) || sum > 1.0) ? sum : 1.0;
+  const bool bad = !(tail <= kTabCoefTol * scale);
+  __syncthreads();
+  fv[t] = c;
+  __syncthreads();
+  if (m < kCtCoef) {
+    double acc = 0.0;
+#pragma unroll
+    for (int q = 0; q < kCtCoef; ++q) acc = __builtin_fma(fv[(t & ~15) + q], kChebMono16.t[q][m], acc);
+    table[kCtHdr + cell * kCtStride + m] = (m == 0 && bad) ? kNaN : acc;
+  }
+}
+
+extern __shared__ __attribute__((aligned(16))) double ct_tab[];  // k_coltab: [kCtCols][kCtTable]
+
 template <int D, int FN, bool F64IO>
-__global__ __launch_bounds__(kCtBlock) void k_coltab(const void* __restrict__ x, int xdt, void* __restrict__ out, int odt,
-                                                     long long R, unsigned P, PeriodicParams pa) {
+__global__ __launch_bounds__(kCtThreads) void k_coltab(const void* __restrict__ x, int xdt, void* __restrict__ out, int odt,
+                                                       long long R, unsigned P, const double* __restrict__ ws,
+                                                       unsigned* __restrict__ counters, unsigned long long* __restrict__ miss_words) {
   using DD = Dist<D>;
   using K = typename DD::K;
   constexpr int NK = sizeof(K) / sizeof(double);
   static_assert(NK <= kCtMaxNK, "k_coltab: K too large");
   constexpr bool QDOM = FN == M355_PPF || FN == M355_ISF;
-  __shared__ double cosv[64];
-  __shared__ double tm[kTabN * kTabN];
-  __shared__ int bad[kTabCells];
+  constexpr TabRoute RT = tab_route_of<DD, FN>();
+  constexpr int U = ct_unroll<FN>();
+  __shared__ unsigned ct_next;                  // the chunk the workgroup has just claimed
   const int t = threadIdx.x;
   const unsigned G = P / kCtCols;
-  const unsigned g = blockIdx.x % G;                                  // this workgroup's column group
-  const long long rb0 = blockIdx.x / G, rbstep = gridDim.x / G;       // (gridDim.x is a multiple of G)
+  const unsigned chunks = (unsigned)((R + ct_chunk_rows<FN>() - 1) / ct_chunk_rows<FN>());
   log_table_init();
-  if (t < kCtCols) {
-    double pp[kMaxParams];
-#pragma unroll
-    for (int q = 0; q < kMaxParams; ++q) pp[q] = (q < DD::NP && pa.ptr[q]) ? pa.ptr[q][g * kCtCols + t] : pa.scalar[q];
-    const K k = DD::derive(pp);
-    const double* kd = reinterpret_cast<const double*>(&k);
-#pragma unroll
-    for (int f = 0; f < NK; ++f) ct_kt[t * kCtMaxNK + f] = kd[f];
-    ct_declined[t] = !coltab_params_ok<DD, FN>(k);
-    ct_logmode[t] = tab_log_mode<DD, FN>(k);
-  }
-  if (t < 64) cosv[t] = kCos32[t];
-  if (t < kTabN * kTabN) tm[t] = kChebMono16.t[t >> 4][t & 15];
-  __syncthreads();
-  if (t < 2 * kCtCols) ct_rng[t] = coltab_range_end<D, FN>((t & 1) != 0, ct_kt + (t >> 1) * kCtMaxNK);  // thread 2c + e
-  __syncthreads();
-  // node values of all tables: j = (table, cell, node); a wavefront's 64 nodes belong to one table
-  for (int j = t; j < kCtCols * kTabCells * kTabN; j += kCtBlock) {
-    const int c = j >> 10, jj = j & 1023;
-    const double wlo = ct_rng[2 * c], whi = ct_rng[2 * c + 1];
-    const double h = (whi - wlo) * (1.0 / kTabCells);
-    double f = kNaN;
-    if (h > 0.0) {  // (a declined column: nothing to evaluate)
-      const double w = wlo + h * ((double)(jj >> 4) + 0.5 + 0.5 * cosv[2 * (jj & 15) + 1]);
-      f = coltab_node<D, FN>(w, ct_kt + c * kCtMaxNK);
-    }
-    ct_coef[c * kCtTable + (jj >> 4) * kTabStride + (jj & 15)] = f;
-  }
-  __syncthreads();
-  // per table: DCT, validation, monomial basis (as k_tab; 1024 entries, two per thread)
+  const int col = t & (kCtCols - 1), rloc = t >> 4;
+  const double* mytab = ct_tab + col * kCtTable;
+  const double* mycoef = mytab + kCtHdr;
+  const unsigned lane_off = (unsigned)rloc * P + (unsigned)col;  // elements; rloc < 64
+  const unsigned home = blockIdx.x % G;
 #pragma unroll 1
-  for (int c = 0; c < kCtCols; ++c) {
-    double* coef = ct_coef + c * kCtTable;
-    double cm[2];
+  for (unsigned s = 0; s < G; ++s) {  // home group first, then the others in order: every workgroup ends after G probes
+    const unsigned g = home + s < G ? home + s : home + s - G;
+    bool loaded = false;
+    K k;
+    double wlo = 0.0, inv_h = 0.0;
+    bool declined = false, logmode = false;
+#pragma unroll 1
+    for (;;) {
+      __syncthreads();  // (the previous chunk's readers of ct_next / the tables are done)
+      if (t == 0) ct_next = atomicAdd(&counters[g], 1u);
+      __syncthreads();
+      const unsigned ch = ct_next;
+      if (ch >= chunks) break;
+      if (!loaded) {
+        // this group's sixteen tables and parameter sets into LDS
+        const double* src = ws + (size_t)g * kCtCols * kCtTable;
+        for (int i = t; i < kCtCols * kCtTable; i += kCtThreads) ct_tab[i] = src[i];
+        __syncthreads();
+        double* kd = reinterpret_cast<double*>(&k);
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
-      const int j = t + r * kCtBlock, cell = j >> 4, m = j & 15;
-      double acc = 0.0;
+        for (int f = 0; f < NK; ++f) kd[f] = mytab[8 + f];
+        wlo = mytab[0];
+        inv_h = mytab[1];
+        declined = mytab[2] != 0.0;  // no table for this column: k_coltab_declined does it, this loop leaves it alone
+        logmode = mytab[3] != 0.0;
+        loaded = true;
+      }
+      auto lookup = [&](double xv) -> double {
+        double wv;
+        if constexpr (QDOM) {
+          const double qq = (FN == M355_ISF) ? 1.0 - xv : xv;
+          wv = tab_logit<DD>(qq);
+          if constexpr (has_tab_node<DD>::value) wv = DD::tab_q_miss(qq) ? kNaN : wv;
+        } else {
+          wv = DD::tab_w(xv, k);
+        }
+        const double s_ = (wv - wlo) * inv_h;
+        const double fi = __builtin_floor(s_);
+        const bool in = (s_ >= 0.0) & (s_ < (double)kCtCells);
+        const double tt = __builtin_fma(2.0, s_ - fi, -1.0);
+        const d2_t* c = reinterpret_cast<const d2_t*>(mycoef + (in ? (int)fi : 0) * kCtStride);
+        d2_t cc = c[kCtCoef / 2 - 1];
+        double r = __builtin_fma(cc.y, tt, cc.x);
 #pragma unroll
-      for (int q = 0; q < kTabN; ++q) acc = __builtin_fma(coef[cell * kTabStride + q], cosv[(m * (2 * q + 1)) & 63], acc);
-      cm[r] = acc * (m == 0 ? 1.0 / 16.0 : 2.0 / 16.0);
-    }
-    __syncthreads();
+        for (int q = kCtCoef / 2 - 2; q >= 0; --q) {
+          cc = c[q];
+          r = __builtin_fma(__builtin_fma(r, tt, cc.y), tt, cc.x);
+        }
+        if constexpr (QDOM && has_tab_ppf_log<DD>::value) {
+          if (__builtin_amdgcn_ballot_w64(logmode) != 0) r = logmode ? exp_(r) : r;  // (skipped when no lane of the wavefront wants it)
+        }
+        if constexpr (has_tab_value_miss<DD>::value) r = DD::template tab_value_miss<RT.fn>(r) ? kNaN : r;
+        r = tab_epilogue<RT.epi>(r);
+        return in ? r : kNaN;
+      };
+      const long long row0 = (long long)ch * ct_chunk_rows<FN>();
+      unsigned long long missed = 0;
+#pragma unroll 1
+      for (int it = 0; it < ct_iters<FN>(); ++it) {
+        const long long rowb = row0 + (long long)it * (U * kCtRows);          // uniform
+        if (rowb >= R) break;
+        const long long ubase = rowb * (long long)P + (long long)g * kCtCols;  // uniform
+        const long long rows_left = R - rowb;                                  // uniform
+        double v[U], r[U];
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
-      const int j = t + r * kCtBlock;
-      coef[(j >> 4) * kTabStride + (j & 15)] = cm[r];
-    }
-    __syncthreads();
-    if (t < kTabCells) {
-      const double* cc = coef + t * kTabStride;
-      double sum = 0.0;
+        for (int u = 0; u < U; ++u) {
+          const long long ub = ubase + (long long)(u * kCtRows) * (long long)P;
+          const bool live = (rloc < rows_left - u * kCtRows) & !declined;
+          if constexpr (F64IO) v[u] = live ? __builtin_nontemporal_load((const double*)x + ub + lane_off) : 0.0;
+          else v[u] = live ? load1(x, xdt, (unsigned long long)(ub + lane_off)) : 0.0;
+        }
 #pragma unroll
-      for (int q = 0; q < kTabN; ++q) sum += __builtin_fabs(cc[q]);
-      const double scale = ((QDOM && !ct_logmode[c]) || sum > 1.0) ? sum : 1.0;
-      const double tail = __builtin_fabs(cc[14]) + __builtin_fabs(cc[15]);
-      bad[t] = !(tail <= kTabCoefTol * scale);
-    }
+        for (int u = 0; u < U; ++u) r[u] = lookup(v[u]);
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
-      const int j = t + r * kCtBlock, cell = j >> 4, m = j & 15;
-      double acc = 0.0;
-#pragma unroll
-      for (int q = 0; q < kTabN; ++q) acc = __builtin_fma(coef[cell * kTabStride + q], tm[q * kTabN + m], acc);
-      cm[r] = acc;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-      const int j = t + r * kCtBlock;
-      coef[(j >> 4) * kTabStride + (j & 15)] = ((j & 15) == 0 && bad[j >> 4]) ? kNaN : cm[r];
-    }
-    __syncthreads();
-  }
-  // rows, in epochs of up to 64 row blocks: coltab_rows (no calls inside: the register allocator is free there) marks
-  // misses with NaN and returns which of its row blocks had any; those are redone by coltab_fixup
-  constexpr int kCtUnroll = ct_unroll<FN>();
-  const long long row_blocks = (R + kCtRows * kCtUnroll - 1) / (kCtRows * kCtUnroll);
-  for (long long rbe = rb0; rbe < row_blocks; rbe += 64 * rbstep) {
-    unsigned long long mask = coltab_rows<D, FN, F64IO>(x, xdt, out, odt, R, P, g, rbe, rbstep, row_blocks);
-    const int col = t & (kCtCols - 1), rloc = t >> 4;
-    while (mask) {
-      const int i = __builtin_ctzll(mask);
-      mask &= mask - 1;
-      const long long rb = rbe + i * rbstep;
-      coltab_fixup<D, FN>(x, xdt, out, odt, rb * (kCtRows * kCtUnroll) + rloc, R, (long long)P, (long long)g * kCtCols + col,
-                          ct_kt + col * kCtMaxNK);
+        for (int u = 0; u < U; ++u) {
+          const long long ub = ubase + (long long)(u * kCtRows) * (long long)P;
+          const bool live = (rloc < rows_left - u * kCtRows) & !declined;
+          const bool hit = r[u] == r[u];
+          if constexpr (F64IO) {
+            if (live & hit) __builtin_nontemporal_store(r[u], (double*)out + ub + lane_off);
+          } else {
+            if (live & hit) store1(out, odt, ub + lane_off, r[u]);
+          }
+          missed |= (unsigned long long)(live & !hit) << (it * U + u);
+        }
+      }
+      miss_words[((size_t)g * chunks + ch) * kCtThreads + t] = missed;
     }
   }
 }
 
-// Columns without a table (Dist<>::tab_ok / tab_ok_fn declined the parameters) are left
-// untouched by k_coltab and done by a second launch: P x kCtDeclChunks workgroups, each re-deriving its column's verdict
-// and returning at once unless the column was declined; a declined column's rows then go
-// through the exact body, parameters wavefront-uniform, spread over kCtDeclChunks workgroups.  (Inside k_coltab such
-// columns would be the work of the one workgroup that owns them: with a run of declined columns -- parameters sorted
-// along the row, a tenth of them out of range -- a handful of CUs did all of it, 58 ms per 1e8.)
+// The misses, redone by the exact body: word w = (group, chunk, thread) of k_coltab, bit = pass * unroll + slot.  x is read
+// again (k_coltab stored nothing where it missed).
+template <int D, int FN>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(min_waves<Dist<D>>::value))) void k_coltab_fix(
+    const void* __restrict__ x, int xdt, void* __restrict__ out, int odt, long long R, unsigned P, PeriodicParams pa,
+    const unsigned long long* __restrict__ miss_words, unsigned long long nwords) {
+  using DD = Dist<D>;
+  using K = typename DD::K;
+  constexpr int U = ct_unroll<FN>();
+  log_table_init();
+  const unsigned chunks = (unsigned)((R + ct_chunk_rows<FN>() - 1) / ct_chunk_rows<FN>());
+  for (unsigned long long w = (unsigned long long)blockIdx.x * kBlock + threadIdx.x; w < nwords; w += (unsigned long long)gridDim.x * kBlock) {
+    unsigned long long mask = miss_words[w];
+    if (mask == 0) continue;
+    const unsigned t = (unsigned)(w % kCtThreads);
+    const unsigned long long gc = w / kCtThreads;
+    const unsigned ch = (unsigned)(gc % chunks), g = (unsigned)(gc / chunks);
+    const unsigned col = g * kCtCols + (t & (kCtCols - 1)), rloc = t >> 4;
+    double pp[kMaxParams];
+#pragma unroll
+    for (int q = 0; q < kMaxParams; ++q) pp[q] = (q < DD::NP && pa.ptr[q]) ? pa.ptr[q][col] : pa.scalar[q];
+    const K k = DD::derive(pp);
+    const long long row0 = (long long)ch * ct_chunk_rows<FN>();
+    while (mask) {
+      const int b = __builtin_ctzll(mask);
+      mask &= mask - 1;
+      const long long row = row0 + (long long)(b / U) * (U * kCtRows) + (long long)(b % U) * kCtRows + rloc;
+      const long long idx = row * (long long)P + col;
+      store1(out, odt, idx, DD::template eval<FN>(load1(x, xdt, (unsigned long long)idx), k));
+    }
+  }
+}
+
+// Columns without a table (Dist<>::tab_ok / tab_ok_fn declined the parameters: flag in the column's table header) are
+// left untouched by k_coltab and done by this launch: P x kCtDeclChunks workgroups, each returning at once unless its
+// column was declined; a declined column's rows then go through the exact body, parameters wavefront-uniform, spread
+// over kCtDeclChunks workgroups.
 constexpr int kCtDeclChunks = 16;
 template <int D, int FN>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(min_waves<Dist<D>>::value))) void k_coltab_declined(
-    const void* __restrict__ x, int xdt, void* __restrict__ out, int odt, long long R, unsigned P, PeriodicParams pa) {
+    const void* __restrict__ x, int xdt, void* __restrict__ out, int odt, long long R, unsigned P, PeriodicParams pa,
+    const double* __restrict__ ws) {
   using DD = Dist<D>;
   using K = typename DD::K;
   constexpr int NK = sizeof(K) / sizeof(double);
   const unsigned c = blockIdx.x % P, chunk = blockIdx.x / P;
+  if (ws[(size_t)c * kCtTable + 2] == 0.0) return;  // k_coltab has this column
   double pp[kMaxParams];
 #pragma unroll
   for (int q = 0; q < kMaxParams; ++q) pp[q] = (q < DD::NP && pa.ptr[q]) ? pa.ptr[q][c] : pa.scalar[q];
   const K k0 = DD::derive(pp);  // (every thread: the same values, no barrier)
-  if (coltab_params_ok<DD, FN>(k0)) return;  // k_coltab has this column
   log_table_init();
   K k;
   {
@@ -1418,10 +1446,22 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(min_wave
   }
 }
 
-// k_coltab needs 144 KiB of dynamic LDS: above the 64 KiB a kernel gets without asking (per device, so asked per launch)
+// k_coltab needs 115 KiB of dynamic LDS: above the 64 KiB a kernel gets without asking.  The attribute is per device and
+// kernel: asked once for each (remembered per instantiation and device ordinal), not per launch -- hipFuncSetAttribute is
+// not a stream operation, so a first call under stream capture is the one that must happen before the capture.
+constexpr int kMaxDevicesTracked = 64;
 template <int D, int FN, bool F64IO> bool coltab_ready() {
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_coltab<D, FN, F64IO>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                             (int)kCtLds) == hipSuccess;
+  static std::atomic<unsigned char> state[kMaxDevicesTracked];  // 0 = not asked, 1 = granted, 2 = refused
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevicesTracked) return false;
+  unsigned char st = state[dev].load(std::memory_order_acquire);
+  if (st == 0) {
+    st = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_coltab<D, FN, F64IO>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                             (int)kCtLds) == hipSuccess ? 1 : 2;
+    if (st == 2) (void)hipGetLastError();
+    state[dev].store(st, std::memory_order_release);
+  }
+  return st == 1;
 }
 
 // ---- Discrete families, scalar parameters, large n: the function of an integer, looked up ------------------------------
@@ -1574,16 +1614,23 @@ __global__ __launch_bounds__(kBlock) void k_generic(GenericOps ops, void* __rest
 template <class T, class = void> struct device_derive : std::false_type {};
 template <class T> struct device_derive<T, std::void_t<decltype(T::kDeviceDerive)>> : std::true_type {};
 
-// k_tab's launch: four workgroups per CU (each builds the table: 1024 exact evaluations), from kTabMinN elements
-// (below, building 1024 tables costs more than evaluating the elements exactly); m355_set_tab_min_n() moves the
-// threshold (tests force the table onto small inputs; a huge value switches it off).
-constexpr int kTabBlocks = 1024;
+// k_tab's launch: five workgroups per CU (24 KiB of LDS each), from kTabMinN elements (below, the table's 3072 exact
+// evaluations and its second launch cost more than evaluating the elements exactly); m355_set_tab_min_n() moves the
+// threshold (tests force the table onto small inputs; a huge value switches it off).  Without a workspace
+// (m355_elemwise instead of m355_elemwise_ws) there is nowhere to build a table: the exact kernels serve.
+constexpr int kTabBlocks = 1280;
 constexpr long long kTabMinN = 1ll << 21;
-inline long long& tab_min_n_ref() {
-  static long long v = [] { const char* e = getenv("M355_TAB_MIN_N"); return e ? atoll(e) : kTabMinN; }();  // (test runs)
+// (an atomic: m355_set_tab_min_n may run beside launches on other threads.  The environment knobs of this file --
+// M355_TAB_MIN_N, M355_TAB_BLOCKS, M355_NO_BINNING -- are for A/B measurements; include/m355_dist.h lists them.)
+inline std::atomic<long long>& tab_min_n_ref() {
+  static std::atomic<long long> v{[] {
+    const char* e = getenv("M355_TAB_MIN_N");
+    const long long t = e ? atoll(e) : kTabMinN;
+    return t < 0 ? kTabMinN : t;
+  }()};
   return v;
 }
-inline long long tab_min_n() { return tab_min_n_ref(); }
+inline long long tab_min_n() { return tab_min_n_ref().load(std::memory_order_relaxed); }
 
 // M355_NO_BINNING=1 in the environment sends the divergent functions through k_scalar (A/B measurements)
 inline bool binning_disabled() {
@@ -1653,16 +1700,21 @@ template <int D, int FN, bool REDUCE> int launch_fn(const LaunchArgs& a) {
       if constexpr (!REDUCE && tab_this<DD, FN>()) {
         bool tab_ok = DD::tab_ok(k);
         if constexpr (has_tab_ok_fn<DD>::value) tab_ok = tab_ok && DD::template tab_ok_fn<FN>(k);
-        if (n >= tab_min_n() && tab_ok && !binning_disabled()) {
+        if (n >= tab_min_n() && tab_ok && !binning_disabled() && a.ews != nullptr && a.ews_doubles >= (size_t)kTabDoubles) {
+          hipLaunchKernelGGL((k_tab_build<D, FN>), dim3(kTabBuildWaves), dim3(64), 0, a.stream, k, a.ews);
           const long long want = tiles < 1 ? 1 : tiles;
-          static const int tb = [] { const char* e = getenv("M355_TAB_BLOCKS"); return e ? atoi(e) : kTabBlocks; }();
+          static const int tb = [] {
+            const char* e = getenv("M355_TAB_BLOCKS");
+            const int t = e ? atoi(e) : kTabBlocks;
+            return t < 1 ? 1 : (t > kMaxBlocks ? kMaxBlocks : t);
+          }();
           const int bb = (int)(want > tb ? tb : want);
           if (a.x.dtype == M355_F64 && a.out_dtype == M355_F64) {  // (cdf / sf too: kFastIO is k_scalar's economy)
             hipLaunchKernelGGL((k_tab<D, FN, true>), dim3(bb), dim3(kBlock), 0, a.stream, a.x.ptr, a.x.dtype, a.out,
-                               a.out_dtype, n, k);
+                               a.out_dtype, n, k, a.ews);
           } else {
             hipLaunchKernelGGL((k_tab<D, FN, false>), dim3(bb), dim3(kBlock), 0, a.stream, a.x.ptr, a.x.dtype, a.out,
-                               a.out_dtype, n, k);
+                               a.out_dtype, n, k, a.ews);
           }
           return (int)hipGetLastError();
         }
@@ -1746,28 +1798,38 @@ template <int D, int FN, bool REDUCE> int launch_fn(const LaunchArgs& a) {
     void* op = a.out;
     long long nn = n;
     if constexpr (!REDUCE && tab_this<DD, FN>()) {
-      // row-periodic parameters, large n: per-column tables (k_coltab); the partial last row, if any, goes on below
+      // row-periodic parameters, large n: per-column tables (k_coltab_build + k_coltab) in the caller's workspace; the
+      // partial last row, if any, goes on below
       const long long R = !all_scalar ? n / (long long)P : 0;
       const unsigned long long G = P / kCtCols;
       const bool f64 = a.x.dtype == M355_F64 && a.out_dtype == M355_F64;
-      // every workgroup builds 16 tables (16384 exact evaluations) for its 16 R / m elements: worth it from ~4 elements
-      // per node, i.e. 4096 rows per workgroup (scaled with m355_set_tab_min_n like the element threshold, so that tests
-      // can force the kernel onto small inputs; P = 1e6 columns of 100 rows stay on k_colbinned)
-      const double m0 = (double)((256 + G - 1) / (G ? G : 1));
-      const bool rows_ok = (double)R * (double)kTabMinN >= 4096.0 * m0 * (double)tab_min_n();
+      // a column's table costs 1024 exact evaluations plus the launches: worth it from ~8192 rows (scaled with
+      // m355_set_tab_min_n like the element threshold, so that tests can force the kernels onto small inputs; a million
+      // columns of a hundred rows stay on k_colbinned)
+      const bool rows_ok = (double)R * (double)kTabMinN >= 8192.0 * (double)tab_min_n();
       if (P % kCtCols == 0 && G >= 1 && G <= 65536ull && R >= 1 && rows_ok && n / 8 >= tab_min_n() && !binning_disabled() &&
+          a.ews != nullptr && a.ews_doubles >= coltab_ws_doubles<FN>(P, R) &&
           (f64 ? coltab_ready<D, FN, true>() : coltab_ready<D, FN, false>())) {
-        const long long row_blocks = (R + kCtRows * ct_unroll<FN>() - 1) / (kCtRows * ct_unroll<FN>());
-        long long m = (256 + (long long)G - 1) / (long long)G;  // one workgroup per CU (LDS)
-        m = m > row_blocks ? row_blocks : m;
+        unsigned* counters = reinterpret_cast<unsigned*>(a.ews + (size_t)P * kCtTable);
+        unsigned long long* miss_words = reinterpret_cast<unsigned long long*>(a.ews + (size_t)P * kCtTable + (G + 2) / 2);
+        const unsigned long long chunks = coltab_chunks<FN>(R);
+        const unsigned long long nwords = G * chunks * kCtThreads;
+        const unsigned nr = (unsigned)((2 * P > G ? 2 * P : G) + kBlock - 1) / kBlock;
+        hipLaunchKernelGGL((k_coltab_ranges<D, FN>), dim3(nr), dim3(kBlock), 0, a.stream, pa, (unsigned)P, a.ews, counters, (unsigned)G);
+        hipLaunchKernelGGL((k_coltab_build<D, FN>), dim3((unsigned)(4 * P)), dim3(kBlock), 0, a.stream, pa, (unsigned)P, a.ews);
+        unsigned long long m = G * chunks;
+        m = m > 256 ? 256 : m;  // one workgroup per CU (LDS)
         if (f64)
-          hipLaunchKernelGGL((k_coltab<D, FN, true>), dim3((unsigned)(G * m)), dim3(kCtBlock), kCtLds, a.stream, xp, a.x.dtype, op,
-                             a.out_dtype, R, (unsigned)P, pa);
+          hipLaunchKernelGGL((k_coltab<D, FN, true>), dim3((unsigned)m), dim3(kCtThreads), kCtLds, a.stream, xp, a.x.dtype, op,
+                             a.out_dtype, R, (unsigned)P, a.ews, counters, miss_words);
         else
-          hipLaunchKernelGGL((k_coltab<D, FN, false>), dim3((unsigned)(G * m)), dim3(kCtBlock), kCtLds, a.stream, xp, a.x.dtype, op,
-                             a.out_dtype, R, (unsigned)P, pa);
+          hipLaunchKernelGGL((k_coltab<D, FN, false>), dim3((unsigned)m), dim3(kCtThreads), kCtLds, a.stream, xp, a.x.dtype, op,
+                             a.out_dtype, R, (unsigned)P, a.ews, counters, miss_words);
+        const unsigned long long fb = (nwords + kBlock - 1) / kBlock;
+        hipLaunchKernelGGL((k_coltab_fix<D, FN>), dim3((unsigned)(fb > 8192 ? 8192 : fb)), dim3(kBlock), 0, a.stream, xp, a.x.dtype, op,
+                           a.out_dtype, R, (unsigned)P, pa, miss_words, nwords);
         hipLaunchKernelGGL((k_coltab_declined<D, FN>), dim3((unsigned)(P * kCtDeclChunks)), dim3(kBlock), 0, a.stream, xp, a.x.dtype,
-                           op, a.out_dtype, R, (unsigned)P, pa);
+                           op, a.out_dtype, R, (unsigned)P, pa, a.ews);
         const int rc = (int)hipGetLastError();
         const long long done = R * (long long)P;
         if (rc != 0 || done == n) return rc;

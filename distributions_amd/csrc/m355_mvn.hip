@@ -26,6 +26,7 @@
 //                  strided solves of matrixnormal (columns of X-M against L_U, then rows against L_V).
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -680,6 +681,269 @@ __global__ __launch_bounds__(64 * kMfmaWaves) void k_solve_mfma(const MfmaArgs a
   }
 }
 
+// ---- Shared covariance, d <= 64: factorisation and solve in ONE launch (round 3) -------------------------------------------
+// k_cholesky + k_solve_mfma cost 28 us + 21 us at config 4's stated size (N = 1e5, d = 64): the factorisation is one
+// workgroup's latency in front of a solve that could not start.  k_mvn_shared removes the first launch: every workgroup
+// (512 threads = two wavefronts per SIMD, one workgroup per CU) factors the covariance itself -- wavefront 0, alone on its
+// SIMD, with k_mvn_tiles' register-tile scheme (16x16 tiles in the MFMA A layout, panels swept in row layout, 40 MFMAs
+// for the trailing updates; ~16k cycles), while the other seven wait at a barrier with their first observation tiles
+// already in flight.  What the solve needs comes straight out of that scheme: a finished tile L_IJ in the A layout IS the
+// A operand of  R_I = Delta_I - sum_{J<I} L_IJ Y_J  (negated once), and the inverses of the four 16x16 diagonal blocks
+// (Y_I = inv(L_II) R_I) are 16 columns x 4 blocks = 64 independent forward substitutions, one per lane.  The operands
+// (NB(NB+1)/2 x 4 doubles per lane: 40 at d = 64) are published through LDS and live in registers for the tile loop,
+// which is k_solve_mfma's blocked substitution: a chain of dependent MFMAs per tile, two wavefronts per SIMD filling the
+// matrix pipe.  Every workgroup computes the same factor from the same code: results do not depend on the grid.
+constexpr int kSharedWaves = 8;
+template <int NB> __host__ __device__ constexpr size_t shared_lds_doubles() {
+  return 64 * 17 * 2 + 64 + (size_t)NB * (NB + 1) / 2 * 256 + 8 + 16 * NB + (size_t)kSharedWaves * 16 * (16 * NB + 4);
+}
+M355_DEV void wave_sync() {  // LDS traffic of ONE wavefront: the hardware keeps its DS operations in order; this keeps the compiler from moving them
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+// Wavefront 0 of k_mvn_shared: Cholesky of the d x d matrix at `src` (padded to 16 NB with an identity block), operands
+// of the solve to fr[(slot(I, J) * 4 + kk) * 64 + lane] (slot = I (I + 1) / 2 + J: -L_IJ for J < I, inv(L_II) for J = I,
+// A layout: element [16 I + (lane & 15)][16 J + (lane >> 4) + 4 kk]), logdet = 2 sum log diag to misc[0].
+template <int NB>
+M355_DEV void shared_factor(const double* __restrict__ src, int d, double* __restrict__ Pm, double* __restrict__ Dg,
+                            double* __restrict__ rd, double* __restrict__ fr, double* __restrict__ misc) {
+  const int lane = threadIdx.x & 63, r16 = lane & 15, g = lane >> 4;
+  const int prow = lane < 16 * NB ? lane : 16 * NB - 1;
+  d4_t T[NB][NB];
+  if (d == 16 * NB) {
+    const int loff = r16 * d + g;
+#pragma unroll
+    for (int J = 0; J < NB; ++J) {
+#pragma unroll
+      for (int I = J; I < NB; ++I) {
+        const double* base = src + (size_t)(16 * I) * d + 16 * J;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) T[I][J][kk] = base[loff + 4 * kk];
+      }
+    }
+  } else {
+#pragma unroll
+    for (int J = 0; J < NB; ++J) {
+#pragma unroll
+      for (int I = J; I < NB; ++I) {
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+          const int row = 16 * I + r16, col = 16 * J + g + 4 * kk;
+          const double v = src[(size_t)(row < d ? row : d - 1) * d + (col < d ? col : d - 1)];
+          T[I][J][kk] = (row < d && col < d) ? v : (row == col ? 1.0 : 0.0);
+        }
+      }
+    }
+  }
+  d4_t Lneg[NB][NB];  // (I > J only)
+  double mydiag = 1.0, myrinv = 1.0;
+#pragma unroll
+  for (int J = 0; J < NB; ++J) {
+#pragma unroll
+    for (int I = J; I < NB; ++I) {
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) Pm[(16 * I + r16) * 17 + g + 4 * kk] = T[I][J][kk];
+    }
+    wave_sync();
+    double u[16], l[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) u[c] = Pm[prow * 17 + c];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+      double piv, rinv;
+      sqrt_rsqrt<false>(readlane_d(u[c], 16 * J + c), piv, rinv);
+      const double lc = u[c] * rinv;
+      l[c] = lc;
+      if (lane == 16 * J + c) {
+        mydiag = piv;
+        myrinv = rinv;
+      }
+#pragma unroll
+      for (int c0 = c + 1; c0 < 16; c0 += 4) {
+        double m[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) m[q] = (c0 + q < 16) ? readlane_d(lc, 16 * J + (c0 + q < 16 ? c0 + q : 15)) : 0.0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          if (c0 + q < 16) u[c0 + q] = __builtin_fma(-lc, m[q], u[c0 + q]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    wave_sync();
+    // row layout back to LDS: lane i holds L[i][16 J + c] (rows of the diagonal block: valid for c <= i - 16 J)
+#pragma unroll
+    for (int c = 0; c < 16; ++c) Pm[lane * 17 + c] = l[c];
+    if (g == J) {
+#pragma unroll
+      for (int c = 0; c < 16; ++c) Dg[lane * 17 + c] = (c <= r16) ? l[c] : 0.0;
+    }
+    wave_sync();
+    if (J + 1 < NB) {
+      d4_t L[NB];
+#pragma unroll
+      for (int I = J + 1; I < NB; ++I) {
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) L[I][kk] = Pm[(16 * I + r16) * 17 + g + 4 * kk];
+        Lneg[I][J] = -L[I];
+      }
+#pragma unroll
+      for (int K = J + 1; K < NB; ++K) {
+#pragma unroll
+        for (int I = K; I < NB; ++I) {
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk) T[I][K] = __builtin_amdgcn_mfma_f64_16x16x4f64(Lneg[K][J][kk], L[I][kk], T[I][K], 0, 0, 0);
+        }
+      }
+      wave_sync();
+    }
+  }
+  if (lane < 16 * NB) rd[lane] = myrinv;
+  {
+    double lg = flog(mydiag);  // identity padding: log 1 = 0; a NaN pivot -> NaN
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) lg += __shfl_xor(lg, o, 64);
+    if (lane == 0) misc[0] = 2.0 * lg;
+  }
+  wave_sync();
+  // inverse of the diagonal blocks: lane (block g, column r16) runs one forward substitution on e_c
+  //   X[c][c] = 1 / L[c][c],  X[r][c] = -(sum_{k=c}^{r-1} L[r][k] X[k][c]) / L[r][r]
+  {
+    const int blk = g < NB ? g : NB - 1, c = r16;
+    const double* Lb = Dg + (16 * blk) * 17;
+    const double* rdb = rd + 16 * blk;
+    double x[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      double acc = 0.0;
+#pragma unroll
+      for (int k = 0; k < r; ++k) acc = __builtin_fma(Lb[r * 17 + k], (k >= c) ? x[k] : 0.0, acc);
+      x[r] = (r == c) ? rdb[r] : (r > c ? -acc * rdb[r] : 0.0);
+    }
+    wave_sync();
+    if (g < NB) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) Dg[(16 * blk + r) * 17 + c] = x[r];
+    }
+    wave_sync();
+  }
+#pragma unroll
+  for (int I = 0; I < NB; ++I) {
+#pragma unroll
+    for (int J = 0; J <= I; ++J) {
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        const double v = (J == I) ? Dg[(16 * I + r16) * 17 + g + 4 * kk] : Lneg[I][J][kk];
+        fr[((I * (I + 1) / 2 + J) * 4 + kk) * 64 + lane] = v;
+      }
+    }
+  }
+}
+
+template <int NB, bool MU_ROWS>
+__global__ __launch_bounds__(64 * kSharedWaves) void k_mvn_shared(const double* __restrict__ cov, const MfmaArgs a) {
+  constexpr int NBLK = NB * (NB + 1) / 2;
+  constexpr int S = 16 * NB + 4;  // staging row stride (as k_solve_mfma)
+  constexpr int NJ = 2 * NB;      // 16-byte loads per lane per tile
+  extern __shared__ double lds[];
+  double* Pm = lds;                     // 64 x 17: wavefront 0's panel buffer (row layout)
+  double* Dg = Pm + 64 * 17;            // 64 x 17: rows of the diagonal blocks, then their inverses
+  double* rd = Dg + 64 * 17;            // 64: 1 / L_ii
+  double* fr = rd + 64;                 // NBLK x 4 x 64 operands of the solve
+  double* misc = fr + NBLK * 256;       // [0] logdet
+  double* mu_s = misc + 8;              // 16 NB (zero padded)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double* st = mu_s + 16 * NB + wave * (16 * S);
+  const int d = a.d;
+  const int tile_elems = 16 * d;
+  const long long total = a.n * (long long)d;
+  const long long ntiles = (a.n + 15) / 16;
+  const long long gstride = (long long)gridDim.x * kSharedWaves;
+  d2_t raw[NJ];
+  auto fetch = [&](long long tile) {
+    const long long base = tile * tile_elems;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int e = 128 * j + 2 * lane;
+      const long long gi = base + e;
+      d2_t v = {0.0, 0.0};
+      if (e < tile_elems) {
+        if (gi + 1 < total) {
+          v = __builtin_nontemporal_load(reinterpret_cast<const d2_t*>(a.x + gi));
+          if (MU_ROWS) v -= __builtin_nontemporal_load(reinterpret_cast<const d2_t*>(a.mu + gi));
+        } else if (gi < total) {
+          v.x = a.x[gi];
+          if (MU_ROWS) v.x -= a.mu[gi];
+        }
+      }
+      raw[j] = v;
+    }
+  };
+  long long tile = (long long)blockIdx.x * kSharedWaves + wave;
+  if (tile < ntiles) fetch(tile);  // in flight during the factorisation
+  for (int e = threadIdx.x; e < 16 * NB; e += blockDim.x) mu_s[e] = (!MU_ROWS && e < d) ? a.mu[e] : 0.0;
+  for (int e = lane; e < 16 * S; e += 64) st[e] = 0.0;  // padding columns stay zero for the whole kernel
+  if (wave == 0) shared_factor<NB>(cov, d, Pm, Dg, rd, fr, misc);  // (wave-uniform branch; no workgroup barrier inside)
+  __syncthreads();
+  double F[NBLK * 4];
+#pragma unroll
+  for (int b = 0; b < NBLK * 4; ++b) F[b] = fr[b * 64 + lane];
+  const double logdet = misc[0];
+  int off0[NJ], off1[NJ];
+  const float invd = 1.0f / (float)d;
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {  // flat element of a tile -> staging offset (e / d through a float reciprocal: exact here)
+    const int e = 128 * j + 2 * lane;
+    const int o0 = (int)(((float)e + 0.5f) * invd), c0 = e - o0 * d;
+    const int o1 = (int)(((float)e + 1.5f) * invd), c1 = (e + 1) - o1 * d;
+    off0[j] = e < tile_elems ? o0 * S + c0 : -1;
+    off1[j] = (e + 1) < tile_elems ? o1 * S + c1 : -1;
+  }
+  const int rbase = (lane & 15) * S + (lane >> 4);
+  for (; tile < ntiles; tile += gstride) {
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      if (off0[j] >= 0) st[off0[j]] = raw[j].x;
+      if (off1[j] >= 0) st[off1[j]] = raw[j].y;
+    }
+    if (tile + gstride < ntiles) fetch(tile + gstride);  // in flight during the MFMA chain below
+    __builtin_amdgcn_wave_barrier();
+    double quad = 0.0;
+    d4_t Y[NB];
+#pragma unroll
+    for (int I = 0; I < NB; ++I) {
+      d4_t acc;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[r] = st[rbase + 16 * I + 4 * r] - mu_s[16 * I + (lane >> 4) + 4 * r];
+#pragma unroll
+      for (int J = 0; J < I; ++J) {
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(F[(I * (I + 1) / 2 + J) * 4 + kk], Y[J][kk], acc, 0, 0, 0);
+      }
+      d4_t y = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) y = __builtin_amdgcn_mfma_f64_16x16x4f64(F[(I * (I + 1) / 2 + I) * 4 + kk], acc[kk], y, 0, 0, 0);
+      Y[I] = y;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) quad = __builtin_fma(y[r], y[r], quad);
+    }
+    __builtin_amdgcn_wave_barrier();
+    quad += __shfl_xor(quad, 16, 64);  // lanes l, l+16, l+32, l+48 hold the four row groups of observation l & 15
+    quad += __shfl_xor(quad, 32, 64);
+    const long long r = tile * 16 + lane;
+    if (lane < 16 && r < a.n) {
+      double v = quad;
+      if (a.mode == 1) {
+        v = -0.5 * (a.c0 + logdet + quad);  // mvnormal.py:82-83
+      } else if (a.mode == 2) {
+        v = a.c0 - 0.5 * (a.nu + (double)d) * flog1p(quad / a.nu) - 0.5 * logdet;  // mvstudentt.py:62-64
+      }
+      a.out[r] = v;
+    }
+  }
+}
+
 // out[b] = scale * sum_{j<m} v[b*m + j] + offset[b % noff]   (matrixnormal's Frobenius norm and normaliser)
 __global__ __launch_bounds__(256) void k_rowsum(const double* __restrict__ v, long long nb, int m, double scale,
                                                 const double* __restrict__ offset, long long noff,
@@ -748,13 +1012,19 @@ template <int NB, bool MU_ROWS> int launch_mfma(const m355::MfmaArgs& a, hipStre
   long long blocks = (ngroups + m355::kMfmaWaves - 1) / m355::kMfmaWaves;
   // one round of resident workgroups (every wavefront pays the fragment / staging prologue once and then walks its
   // groups): workgroups per CU from the occupancy calculator (registers and LDS decide: 1 at NB = 4, up to 4 at NB = 1)
-  static const long long resident = [&] {
-    int per_cu = 0, dev = 0, cus = 0;
+  // (remembered per device ordinal: occupancy and CU count belong to the device that is current)
+  static std::atomic<long long> resident_of[64];
+  int dev_now = 0;
+  if (hipGetDevice(&dev_now) != hipSuccess || dev_now < 0 || dev_now >= 64) dev_now = 0;
+  long long resident = resident_of[dev_now].load(std::memory_order_relaxed);
+  if (resident == 0) {
+    int per_cu = 0, cus = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 64 * m355::kMfmaWaves, lds) != hipSuccess || per_cu < 1) per_cu = 1;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev_now) != hipSuccess || cus < 1) cus = 256;
     (void)hipGetLastError();
-    return (long long)per_cu * cus;
-  }();
+    resident = (long long)per_cu * cus;
+    resident_of[dev_now].store(resident, std::memory_order_relaxed);
+  }
   long long cap = resident;
   if (const char* e = getenv("M355_MVN_BLOCKS")) {  // A/B knob for grid sweeps; ignored unless a positive count
     const long long v = atoll(e);
@@ -763,6 +1033,39 @@ template <int NB, bool MU_ROWS> int launch_mfma(const m355::MfmaArgs& a, hipStre
   if (blocks > cap) blocks = cap;
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64 * m355::kMfmaWaves), lds, s, a);
   return launched();
+}
+// k_mvn_shared: one workgroup per CU at most (its wavefront 0 wants a SIMD to itself while it factors), 8 tiles per round
+template <int NB, bool MU_ROWS> int launch_shared(const double* cov, const m355::MfmaArgs& a, hipStream_t s) {
+  auto kern = m355::k_mvn_shared<NB, MU_ROWS>;
+  const size_t lds = m355::shared_lds_doubles<NB>() * sizeof(double);
+  static std::atomic<unsigned char> state[64];  // per device: 0 = not asked, 1 = ready, 2 = refused
+  static std::atomic<int> cus_of[64];
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return fail(M355_ERR_LAUNCH, "hipGetDevice failed");
+  if (state[dev].load(std::memory_order_acquire) == 0) {
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+    cus_of[dev].store(cus);
+    const bool ok = lds <= 64 * 1024 ||
+                    hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
+    (void)hipGetLastError();
+    state[dev].store(ok ? 1 : 2, std::memory_order_release);
+  }
+  if (state[dev].load(std::memory_order_acquire) != 1) return fail(M355_ERR_LAUNCH, "k_mvn_shared: %zu bytes of LDS refused", lds);
+  const long long ntiles = (a.n + 15) / 16;
+  long long blocks = (ntiles + m355::kSharedWaves - 1) / m355::kSharedWaves;
+  const long long cap = cus_of[dev].load();
+  if (blocks > cap) blocks = cap;
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64 * m355::kSharedWaves), lds, s, cov, a);
+  return launched();
+}
+template <bool MU_ROWS> int run_shared(const double* cov, const m355::MfmaArgs& a, hipStream_t s) {
+  switch (m355::nblk16(a.d)) {
+    case 1: return launch_shared<1, MU_ROWS>(cov, a, s);
+    case 2: return launch_shared<2, MU_ROWS>(cov, a, s);
+    case 3: return launch_shared<3, MU_ROWS>(cov, a, s);
+    default: return launch_shared<4, MU_ROWS>(cov, a, s);
+  }
 }
 template <bool MU_ROWS> int run_mfma(const m355::MfmaArgs& a, hipStream_t s) {
   switch (m355::nblk16(a.d)) {
@@ -775,6 +1078,11 @@ template <bool MU_ROWS> int run_mfma(const m355::MfmaArgs& a, hipStream_t s) {
     case 7: return launch_mfma<7, MU_ROWS>(a, s);
     default: return launch_mfma<8, MU_ROWS>(a, s);
   }
+}
+// M355_MVN_TWO_LAUNCH=1: the round-2 path (k_cholesky + k_solve_mfma) for d <= 64 too -- A/B measurements and tests
+bool two_launch_path() {
+  static const bool on = [] { const char* e = getenv("M355_MVN_TWO_LAUNCH"); return e && e[0] == '1'; }();
+  return on;
 }
 int run_solve(const m355::SolveArgs& a, bool shared, hipStream_t s) {
   const long long blocks = (a.n + m355::kSolveThreads - 1) / m355::kSolveThreads;
@@ -813,6 +1121,12 @@ extern "C" int m355_mvn_logpdf(int kind, int64_t n, int d, const double* x, cons
     const double lt = kind == 1 ? lgamma((nu + d) / 2.0) - lgamma(nu / 2.0) - 0.5 * d * log(nu * 3.14159265358979323846) : 0.0;
     FusedArgs fa{x, mu, (long long)mu_stride, out, kind == 0 ? 1 : 2, nu, kind == 0 ? lognorm_n0 : lt, (long long)n};
     return run_batched(cov, n, d, fa, s);
+  }
+  if (mfma && d <= 64 && !two_launch_path()) {
+    // shared covariance, d <= 64: factorisation and solve in one launch (k_mvn_shared); the workspace is not touched
+    const double lt = kind == 1 ? lgamma((nu + d) / 2.0) - lgamma(nu / 2.0) - 0.5 * d * log(nu * 3.14159265358979323846) : 0.0;
+    MfmaArgs m{x, mu, nullptr, nullptr, out, (long long)n, d, kind == 0 ? 1 : 2, nu, kind == 0 ? lognorm_n0 : lt};
+    return mu_stride == 0 ? run_shared<false>(cov, m, s) : run_shared<true>(cov, m, s);
   }
   int rc = run_cholesky(cov, ncov, d, ws, frags, s);
   if (rc != M355_OK) return rc;

@@ -1,6 +1,6 @@
 """Allocation-free launch helpers over the C-ABI for callers that own their device buffers
 (benchmarks, sharded log-likelihood loops): x and out are contiguous torch CUDA tensors, parameters
-are Python scalars.  Work is enqueued on torch's current stream; nothing synchronises."""
+are Python scalars or float64 CUDA tensors of shape (P,) (row-periodic: x viewed as (n / P, P)).  Work is enqueued on torch's current stream; nothing synchronises."""
 
 from __future__ import annotations
 
@@ -18,7 +18,11 @@ def _operands(x, params, torch):
     ops = (Operand * (1 + len(params)))()
     ops[0].ptr, ops[0].scalar, ops[0].div, ops[0].mod, ops[0].dtype = x.data_ptr(), 0.0, 1, x.numel(), _dt(x, torch)
     for j, p in enumerate(params, start=1):
-        ops[j].ptr, ops[j].scalar, ops[j].div, ops[j].mod, ops[j].dtype = None, float(p), 1, 1, F64
+        if hasattr(p, "data_ptr"):  # a contiguous float64 CUDA tensor of shape (P,): row-periodic along the flat index
+            assert p.is_cuda and p.is_contiguous() and p.dtype == torch.float64 and p.dim() == 1
+            ops[j].ptr, ops[j].scalar, ops[j].div, ops[j].mod, ops[j].dtype = p.data_ptr(), 0.0, 1, p.numel(), F64
+        else:
+            ops[j].ptr, ops[j].scalar, ops[j].div, ops[j].mod, ops[j].dtype = None, float(p), 1, 1, F64
     return ops
 
 
@@ -26,7 +30,17 @@ def _p(ops, j):
     return ctypes.cast(ctypes.byref(ops, j * ctypes.sizeof(Operand)), ctypes.POINTER(Operand))
 
 
-def elemwise_into(dist: str, fn: str, x, params, out) -> None:
+def elemwise_workspace(device):
+    """A workspace for elemwise_into's launch-time tables (m355_elemwise_workspace_bytes(): 32 MiB).  One per stream
+    that may run concurrently with others; calls on one stream may share it."""
+    import torch
+
+    return torch.empty(int(_lib.lib().m355_elemwise_workspace_bytes()), dtype=torch.uint8, device=device)
+
+
+def elemwise_into(dist: str, fn: str, x, params, out, workspace=None) -> None:
+    """out[i] = <dist>.<fn>(x[i], *params); `out` may be `x` itself.  With a `workspace` (elemwise_workspace) the
+    library may use its launch-time tables (m355_elemwise_ws); without one the exact kernels serve."""
     import torch
 
     assert x.is_cuda and out.is_cuda and x.is_contiguous() and out.is_contiguous()
@@ -34,8 +48,10 @@ def elemwise_into(dist: str, fn: str, x, params, out) -> None:
     ops = _operands(x, params, torch)
     stream = torch.cuda.current_stream(x.device).cuda_stream
     with torch.cuda.device(x.device):  # the launch goes to HIP's current device: make it x's
-        _lib.check(_lib.lib().m355_elemwise(DIST[dist], FN[fn], _dt(out, torch), x.numel(), _p(ops, 0),
-                                            len(params), _p(ops, 1), out.data_ptr(), stream))
+        _lib.check(_lib.lib().m355_elemwise_ws(DIST[dist], FN[fn], _dt(out, torch), x.numel(), _p(ops, 0),
+                                               len(params), _p(ops, 1), out.data_ptr(),
+                                               workspace.data_ptr() if workspace is not None else None,
+                                               workspace.numel() if workspace is not None else 0, stream))
 
 
 def sumlogp_workspace(device):

@@ -138,16 +138,43 @@ int m355_device_count(void);
  */
 int m355_elemwise(int dist, int fn, int out_dtype, int64_t n, const m355_operand* x, int nparams,
                   const m355_operand* params, void* out, void* stream);
+/*
+ * x and out: `out` may be the very buffer of x (same address, same dtype: every element is read before its result is
+ * written); any other overlap of the two ranges is undefined.  Parameter arrays must not overlap out.
+ *
+ * m355_elemwise_ws: the same call with a device workspace (m355_elemwise_workspace_bytes() bytes recommended, 8-byte
+ * aligned, NULL / 0 allowed).  From `min_n` elements on (m355_set_tab_min_n below) the library evaluates logcdf / logsf /
+ * cdf / sf / ppf / isf of gamma, beta, studentt (and halfstudentt, chisquared, inversegamma, scaledinversechisquared,
+ * betascaled) from tables that a first launch builds from the exact bodies (k_tab_build / k_coltab_build, DESIGN.md
+ * section 3: cells that do not reach 1e-14 and arguments outside the table take the exact body) -- and the tables live
+ * in this workspace: 20 KiB for scalar parameters; for row-periodic parameters (x of shape (R, P), parameters of shape
+ * (P,), P a multiple of 16) 7360 bytes per column plus one bit per element (the elements the tables could not answer,
+ * which a last launch redoes by the exact body).  Without a workspace, or with one that is
+ * too small for the case at hand, the exact kernels serve (same results within the parity bar, slower).  The workspace
+ * is scratch: its contents mean nothing after the call, but calls that may run CONCURRENTLY (different streams) need a
+ * workspace each; calls on one stream may share one.  m355_elemwise(...) is m355_elemwise_ws(..., NULL, 0, stream).
+ */
+size_t m355_elemwise_workspace_bytes(void);
+/* what a call with n elements needs exactly: period = 0 for scalar parameters, else the length P of the row-periodic
+ * parameter arrays (0 is returned when the library has no table kernel for that period) */
+size_t m355_elemwise_workspace_bytes_for(int64_t n, int64_t period);
+int m355_elemwise_ws(int dist, int fn, int out_dtype, int64_t n, const m355_operand* x, int nparams,
+                     const m355_operand* params, void* out, void* workspace, size_t workspace_bytes, void* stream);
 
 /*
- * Tuning knob of m355_elemwise, no counterpart in the reference.  With scalar parameters and at least `min_n`
- * elements, logcdf / logsf / cdf / sf / ppf / isf of gamma, beta, studentt (and halfstudentt, chisquared, inversegamma,
- * scaledinversechisquared, betascaled) are evaluated from a table that every workgroup builds from the exact bodies at
- * launch (k_tab; cells that do not reach 1e-14 and arguments outside the table take the exact
- * body), and the same functions of the discrete families from tables of the exact values over a window of integers
- * (k_dtab: bit-identical results).  With row-periodic parameters (x of shape (R, P), parameters of shape (P,), P a
- * multiple of 16) the same tables are built per column from 8 * min_n elements (k_coltab).  Returns the previous threshold; min_n < 0 restores the default (2^21),
- * INT64_MAX switches the table off.  Process-wide, not synchronised with launches in flight on other threads.
+ * Tuning knob of m355_elemwise_ws, no counterpart in the reference: the element count from which the launch-time tables
+ * are used -- scalar parameters: n >= min_n; row-periodic parameters: n >= 8 * min_n (and >= 8192 rows at the default);
+ * also the threshold of the discrete families' lookup kernels (k_dtab: exact values over a window of integers,
+ * bit-identical results, no workspace).  Returns the previous threshold; min_n < 0 restores the default (2^21),
+ * INT64_MAX switches the tables off.  Process-wide (an atomic: safe beside launches on other threads, which see the old
+ * or the new value).
+ *
+ * Environment variables read once per process, for A/B measurements only (none changes results beyond the parity bar):
+ *   M355_TAB_MIN_N=<n>       initial value of the threshold above
+ *   M355_TAB_BLOCKS=<b>      grid of k_tab (default 1280, clamped to [1, 32768])
+ *   M355_NO_BINNING=1        the divergent functions through k_scalar / k_periodic: no LDS sort, no tables
+ *   M355_MVN_BLOCKS=<b>      grid cap of k_solve_mfma (shared covariance, d > 64)
+ *   M355_MVN_TWO_LAUNCH=1    shared covariance, d <= 64: k_cholesky + k_solve_mfma instead of the fused k_mvn_shared
  */
 int64_t m355_set_tab_min_n(int64_t min_n);
 
@@ -168,9 +195,12 @@ int m355_sumlogp(int dist, int fn, int64_t n, const m355_operand* x, int nparams
  * for callers that cannot allocate device memory around the call -- code under HIP graph capture, tight serving
  * loops, harnesses that forbid hipMalloc.  The per-workgroup partials live in a file-scope `static __device__`
  * array of the library (4096 doubles = 32 KiB on every GPU the library runs on, held until the process ends); its
- * per-device address is looked up once (hipGetSymbolAddress, first call on that device, device current).  Same
- * kernels, grid and fixed-order final pass as m355_sumlogp, so *out_sum is bit-identical to it.  The call itself
- * performs no hipMalloc / hipFree and never synchronises.
+ * per-device address is looked up once (hipGetSymbolAddress, first call on that device, device current).  With scalar
+ * parameters: the same kernels, grid and fixed-order final pass as m355_sumlogp, so *out_sum is bit-identical to it.
+ * With row-periodic parameters the 32 KiB array has no room for m355_sumlogp's table of derived constants
+ * (k_derive_table + k_periodic_prod need the 256 KiB workspace): this entry point keeps k_periodic with its LDS table,
+ * on another grid and in another order of accumulation -- the same total within 1e-12 * sum |term|, not bit for bit.
+ * The call itself performs no hipMalloc / hipFree and never synchronises.
  *   - n above M355_SUMLOGP_STATIC_MAX_N is rejected with M355_ERR_WORKSPACE (use m355_sumlogp, or split the range
  *     and add the totals).
  *   - every call on one GPU shares that GPU's array: calls that overlap in time on one GPU (different streams or
@@ -248,8 +278,8 @@ int m355_moment(int dist, int stat, int out_dtype, int64_t n, int nparams, const
  * Multivariate normal / Student t log-density: out[r] = logpdf(x[r, :]) for r in [0, n), x row-major
  * n x d (d <= 128).  Replaces mvnormal.logpdf (mvnormal.py:80-83 with quaddist_chol :17-37 and
  * _logdet_from_cholesky :9-14) for kind 0 and mvstudentt.logpdf (mvstudentt.py:58-68) for kind 1:
- * Cholesky of every covariance (one workgroup each, in LDS), one forward substitution per
- * observation row, sum of squares and the epilogue fused.  mu: d doubles shared by all rows
+ * Cholesky of every covariance, one forward substitution per observation row, sum of squares and the epilogue
+ * fused (shared covariance with d <= 64: factorisation and solve in one launch, k_mvn_shared).  mu: d doubles shared by all rows
  * (mu_stride 0) or one row per observation (mu_stride d).  cov: ncov matrices d x d; observation
  * r uses matrix (r / cov_div) % cov_mod (shared covariance: ncov = 1).  A covariance that is not
  * positive definite yields NaN, as the reference does (posdef is ignored, mvnormal.py:81).

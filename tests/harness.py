@@ -362,8 +362,10 @@ CANCELLATION_FNS = {
 # The allowance is exactly that model -- 4 ulp of x through the amplification plus 2e-16 nu -- and vanishes for the
 # parameters the reference tests and BASELINE.json's configs use (nu <= 100: < 2e-14).
 def _student_window(params, exp, halfstudentt):
-    nu = float(params[0])
-    mu, sigma = (0.0, float(params[1])) if halfstudentt else (float(params[1]), float(params[2]))
+    # (parameters may be arrays that broadcast against exp: row-periodic parameter tests)
+    nu = np.asarray(params[0], dtype=np.float64)
+    mu, sigma = (0.0, np.asarray(params[1], dtype=np.float64)) if halfstudentt else (
+        np.asarray(params[1], dtype=np.float64), np.asarray(params[2], dtype=np.float64))
     with np.errstate(all="ignore"):
         t = np.abs((np.asarray(exp, dtype=np.float64) - mu) / sigma)
         delta = t * t / (nu + t * t)
@@ -374,7 +376,7 @@ def _student_window(params, exp, halfstudentt):
 def ppf_close(name, fn, params, got, exp):
     """close() at 1e-12 plus, for quantiles of studentt / halfstudentt, the modelled allowance above."""
     ok = close(got, exp, 1e-12)
-    if fn in ("ppf", "isf") and name in ("studentt", "halfstudentt") and params is not None and np.ndim(params[0]) == 0:
+    if fn in ("ppf", "isf") and name in ("studentt", "halfstudentt") and params is not None:
         with np.errstate(all="ignore"):
             extra = _student_window(params, exp, name == "halfstudentt")
             ok |= np.abs(np.asarray(got) - np.asarray(exp)) <= 1e-12 * np.maximum(1.0, np.abs(exp)) + extra

@@ -198,6 +198,10 @@ template <class T, class = void> struct hm_has_node : std::false_type {};
 template <class T> struct hm_has_node<T, std::void_t<decltype(T::kTabNode)>> : std::true_type {};
 template <class T, class = void> struct hm_has_cap : std::false_type {};
 template <class T> struct hm_has_cap<T, std::void_t<decltype(&T::tab_cap)>> : std::true_type {};
+template <class T, class = void> struct hm_has_ppf_node : std::false_type {};
+template <class T> struct hm_has_ppf_node<T, std::void_t<decltype(&T::tab_ppf_node)>> : std::true_type {};
+template <class T, class = void> struct hm_has_ppf_log : std::false_type {};
+template <class T> struct hm_has_ppf_log<T, std::void_t<decltype(&T::tab_ppf_log)>> : std::true_type {};
 template <int D, int FN> static int tab_build(const double* p, double* out) {
   using DD = Dist<D>;
   if constexpr (!hm_has_tab<DD>::value) {
@@ -250,6 +254,122 @@ extern "C" int hm_tab_build(int dist, int fn, const double* p, double* out) {
     return -1;
     M355_DIST_LIST(HM_TAB)
 #undef HM_TAB
+  }
+  return -1;
+}
+
+// The table build of k_tab_build (m355_elemwise.h) with the format as arguments -- ncell cells, nn Chebyshev nodes per
+// cell, the first nc coefficients kept -- restated on the host, quantiles included: per cell out[2 + cell] = (sum of the
+// |dropped or last two| coefficients) / scale, and err[cell] = the largest |interpolant - node function| / scale over
+// 33 points of the cell (the truth against which the validation rule is judged).
+template <int D, int FN> static double hm_tab_node(double w, const typename Dist<D>::K& k) {
+  using DD = Dist<D>;
+  constexpr bool QDOM = FN == M355_PPF || FN == M355_ISF;
+  if constexpr (QDOM) {
+    if constexpr (hm_has_ppf_node<DD>::value) {
+      return DD::tab_ppf_node(w, k);
+    } else {
+      const double e = exp_(-__builtin_fabs(w));
+      const double p = m355::fdiv(e, 1.0 + e);
+      double f;
+      if (w <= 0.0) {
+        f = DD::template eval<M355_PPF>(p, k);
+      } else {
+        f = DD::template eval<M355_PPF>(1.0 - p, k);
+        const double lp = flog(p);
+        for (int it = 0; it < 2; ++it) {
+          const double lsf = DD::template eval<M355_LOGSF>(f, k);
+          const double step = (lsf - lp) * exp_(lsf - DD::template eval<M355_LOGPDF>(f, k));
+          if (step - step == 0.0) f += step;
+        }
+      }
+      if constexpr (hm_has_ppf_log<DD>::value) {
+        if (DD::tab_ppf_log(k)) f = flog(f);
+      }
+      return f;
+    }
+  } else if constexpr (hm_has_node<DD>::value) {
+    return DD::template tab_node<FN>(w, k);
+  } else {
+    return DD::template eval<FN>(DD::tab_x(w, k), k);
+  }
+}
+template <int D, int FN> static int tab_build2(const double* p, int ncell, int nn, int nc, double* out, double* err) {
+  using DD = Dist<D>;
+  if constexpr (!hm_has_tab<DD>::value) {
+    return -2;
+  } else {
+    constexpr bool QDOM = FN == M355_PPF || FN == M355_ISF;
+    const auto k = DD::derive(p);
+    if (!DD::tab_ok(k)) return 1;
+    double rng[2];
+    for (int e = 0; e < 2; ++e) {
+      double tq = 1e-9, we = kNaN;
+      if (QDOM) {
+        we = e == 0 ? -20.723265835946928 : 20.723265835946928;
+      } else {
+        for (int it = 0; it < 4 && !(we - we == 0.0); ++it, tq *= 100.0)
+          we = DD::tab_w(DD::template eval<M355_PPF>(e == 0 ? tq : 1.0 - tq, k), k);
+        if constexpr (hm_has_cap<DD>::value) {
+          if (!(we - we == 0.0)) we = DD::tab_w(DD::tab_cap(e == 1, k), k);
+        }
+      }
+      rng[e] = we;
+    }
+    out[0] = rng[0];
+    out[1] = rng[1];
+    const double wlo = rng[0], h = (rng[1] - rng[0]) / ncell;
+    const double pi = 3.14159265358979323846;
+    bool logmode = false;
+    if constexpr (QDOM && hm_has_ppf_log<DD>::value) logmode = DD::tab_ppf_log(k);
+    for (int cell = 0; cell < ncell; ++cell) {
+      double f[32], c[32];
+      for (int j = 0; j < nn; ++j) {
+        const double w = wlo + h * (cell + 0.5 + 0.5 * __builtin_cos(pi * (2 * j + 1) / (2.0 * nn)));
+        f[j] = hm_tab_node<D, FN>(w, k);
+      }
+      double sum = 0.0;
+      for (int m = 0; m < nn; ++m) {
+        double acc = 0.0;
+        for (int j = 0; j < nn; ++j) acc += f[j] * __builtin_cos(pi * m * (2 * j + 1) / (2.0 * nn));
+        c[m] = acc * (m == 0 ? 1.0 / nn : 2.0 / nn);
+        sum += __builtin_fabs(c[m]);
+      }
+      const double scale = ((QDOM && !logmode) || sum > 1.0) ? sum : 1.0;
+      double tail = 0.0;
+      if (nc < nn) for (int m = nc; m < nn; ++m) tail += __builtin_fabs(c[m]);
+      else tail = __builtin_fabs(c[nn - 2]) + __builtin_fabs(c[nn - 1]);
+      out[2 + cell] = tail / scale;
+      double worst = 0.0;
+      for (int s = 0; s <= 32; ++s) {
+        const double t = -1.0 + s / 16.0;
+        double b0 = 0.0, b1 = 0.0;  // Clenshaw over the kept coefficients
+        for (int m = nc - 1; m >= 1; --m) {
+          const double b = c[m] + 2.0 * t * b0 - b1;
+          b1 = b0;
+          b0 = b;
+        }
+        const double v = c[0] + t * b0 - b1;
+        const double w = wlo + h * (cell + 0.5 + 0.5 * t);
+        const double e = __builtin_fabs(v - hm_tab_node<D, FN>(w, k)) / scale;
+        if (e > worst || e != e) worst = e;
+      }
+      err[cell] = worst;
+    }
+    return 0;
+  }
+}
+extern "C" int hm_tab_build2(int dist, int fn, const double* p, int ncell, int nn, int nc, double* out, double* err) {
+  if (nn > 32 || nc > nn || nc < 2) return -3;
+  switch (dist) {
+#define HM_TAB2(ID, name, np)                                                                   \
+  case ID:                                                                                      \
+    if (fn == M355_LOGCDF) return tab_build2<ID, M355_LOGCDF>(p, ncell, nn, nc, out, err);      \
+    if (fn == M355_LOGSF) return tab_build2<ID, M355_LOGSF>(p, ncell, nn, nc, out, err);        \
+    if (fn == M355_PPF) return tab_build2<ID, M355_PPF>(p, ncell, nn, nc, out, err);            \
+    return -1;
+    M355_DIST_LIST(HM_TAB2)
+#undef HM_TAB2
   }
   return -1;
 }

@@ -731,8 +731,9 @@ def test_colbinned_kernel_equals_periodic_kernel(gpu, name, fn, P):
         else:
             ops[j].ptr, ops[j].scalar, ops[j].div, ops[j].mod, ops[j].dtype = p.data_ptr(), 0.0, 1, P, F64
     at = lambda k: ctypes.cast(ctypes.byref(ops, k * ctypes.sizeof(Operand)), ctypes.POINTER(Operand))
-    _lib.check(_lib.lib().m355_elemwise(DIST[name], FN[fn], F64, n, at(0), len(params), at(1), out.data_ptr(),
-                                        torch.cuda.current_stream(gpu).cuda_stream))
+    wsb = torch.empty(int(_lib.lib().m355_elemwise_workspace_bytes()), dtype=torch.uint8, device=gpu)
+    _lib.check(_lib.lib().m355_elemwise_ws(DIST[name], FN[fn], F64, n, at(0), len(params), at(1), out.data_ptr(),
+                                           wsb.data_ptr(), wsb.numel(), torch.cuda.current_stream(gpu).cuda_stream))
     flat = out.cpu().numpy()
     assert np.array_equal(flat[: rows * P].reshape(rows, P), big, equal_nan=True)
     tail_params = [np.asarray(p)[:tail] if np.ndim(p) else p for p in params]
@@ -805,6 +806,7 @@ def test_coltab_kernel(gpu, name, fn, P):
     x = np.ascontiguousarray(x).ravel()[:n]
     xt = torch.from_numpy(x).to(gpu)
     keep = [torch.from_numpy(np.ascontiguousarray(p)).to(gpu) for p in params]
+    wsb = torch.empty(int(L.m355_elemwise_workspace_bytes()), dtype=torch.uint8, device=gpu)  # k_coltab's tables live here
 
     def flat_call():
         out = torch.empty(n, dtype=torch.float64, device=gpu)
@@ -813,8 +815,8 @@ def test_coltab_kernel(gpu, name, fn, P):
         for j, p in enumerate(keep, start=1):
             ops[j].ptr, ops[j].scalar, ops[j].div, ops[j].mod, ops[j].dtype = p.data_ptr(), 0.0, 1, P, F64
         at = lambda k: ctypes.cast(ctypes.byref(ops, k * ctypes.sizeof(Operand)), ctypes.POINTER(Operand))
-        _lib.check(L.m355_elemwise(DIST[name], FN[fn], F64, n, at(0), len(params), at(1), out.data_ptr(),
-                                   torch.cuda.current_stream(gpu).cuda_stream))
+        _lib.check(L.m355_elemwise_ws(DIST[name], FN[fn], F64, n, at(0), len(params), at(1), out.data_ptr(),
+                                      wsb.data_ptr(), wsb.numel(), torch.cuda.current_stream(gpu).cuda_stream))
         return out.cpu().numpy()
 
     old = L.m355_set_tab_min_n(2**62)
@@ -874,8 +876,8 @@ def test_coltab_kernel(gpu, name, fn, P):
             for j, p in enumerate(keep, start=1):
                 ops[j].ptr, ops[j].scalar, ops[j].div, ops[j].mod, ops[j].dtype = p.data_ptr(), 0.0, 1, P, F64
             at = lambda k: ctypes.cast(ctypes.byref(ops, k * ctypes.sizeof(Operand)), ctypes.POINTER(Operand))
-            _lib.check(L.m355_elemwise(DIST[name], FN[fn], F32, n, at(0), len(params), at(1), out.data_ptr(),
-                                       torch.cuda.current_stream(gpu).cuda_stream))
+            _lib.check(L.m355_elemwise_ws(DIST[name], FN[fn], F32, n, at(0), len(params), at(1), out.data_ptr(),
+                                          wsb.data_ptr(), wsb.numel(), torch.cuda.current_stream(gpu).cuda_stream))
             return out.cpu().numpy().astype(np.float64)
 
         old = L.m355_set_tab_min_n(2**62)
