@@ -902,6 +902,21 @@ template <> struct Dist<M355_BETASCALED> {
   }
   static M355_DEV double tab_w(double x, const K& k) { return flog_tab_or_nan(fdiv_t<1, true>(x - k.lo, k.hi - x)); }
   static M355_DEV double tab_x(double w, const K& k) { return __builtin_fma(k.w, fdiv(1.0, 1.0 + exp_(-w)), k.lo); }
+  // Node values from the position p = sigmoid(w) in (0, 1) and its complement, both formed directly (as Dist<M355_BETA>):
+  // x = lower + p (upper - lower) rounds at 1.1e-16 max(|lower|, |upper|), which next to an end of the support is a
+  // relative error of the position itself -- 1.5e-12 at p = 2e-5 on (-1, 3), i.e. 3e-12 in logcdf with alpha = 2 (round 3:
+  // tests/test_gpu_tables_full.py::test_tabulated_cdf_sf_relative_accuracy measured 1.6e-12) -- while the reference's
+  // (x - lower) / (upper - lower) of a DATA point is exact to an ulp of the position.
+  static constexpr bool kTabNode = true;
+  template <int FN> static M355_DEV double tab_node(double w, const K& k) {
+    const double e = exp_(-__builtin_fabs(w));
+    const double sm = fdiv(e, 1.0 + e);
+    const double p = (w < 0.0) ? sm : 1.0 - sm, q = (w < 0.0) ? 1.0 - sm : sm;
+    constexpr bool UP = FN == M355_LOGSF || FN == M355_SF;
+    const double I = UP ? betainc_xy(k.b, k.a, q, p, k.lbeta) : betainc_xy(k.a, k.b, p, q, k.lbeta);
+    if (FN == M355_LOGCDF || FN == M355_LOGSF) return flog(I);
+    return (FN == M355_SF) ? 1.0 - betainc_xy(k.a, k.b, p, q, k.lbeta) : I;  // betascaled.py:88-89: sf = 1 - cdf
+  }
   // sum of logpdf: sum log(x - lo), sum log(hi - x) as LogProds (protocol of Dist<M355_GAMMA>::SumAcc)
   struct SumAcc {
     LogProd px, pc;

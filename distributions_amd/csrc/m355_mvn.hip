@@ -705,10 +705,16 @@ M355_DEV void wave_sync() {  // LDS traffic of ONE wavefront: the hardware keeps
 // Wavefront 0 of k_mvn_shared: Cholesky of the d x d matrix at `src` (padded to 16 NB with an identity block), operands
 // of the solve to fr[(slot(I, J) * 4 + kk) * 64 + lane] (slot = I (I + 1) / 2 + J: -L_IJ for J < I, inv(L_II) for J = I,
 // A layout: element [16 I + (lane & 15)][16 J + (lane >> 4) + 4 kk]), logdet = 2 sum log diag to misc[0].
-template <int NB>
+#ifndef M355_SHARED_VARIANT
+#define M355_SHARED_VARIANT 0
+#endif
+// `after_load` runs once the loads of the covariance are in flight (the caller's first observation tile: one memory
+// latency for both).
+template <int NB, class AfterLoad>
 M355_DEV void shared_factor(const double* __restrict__ src, int d, double* __restrict__ Pm, double* __restrict__ Dg,
-                            double* __restrict__ rd, double* __restrict__ fr, double* __restrict__ misc) {
+                            double* __restrict__ rd, double* __restrict__ fr, double* __restrict__ misc, AfterLoad after_load) {
   const int lane = threadIdx.x & 63, r16 = lane & 15, g = lane >> 4;
+  M355_TICK(0);
   const int prow = lane < 16 * NB ? lane : 16 * NB - 1;
   d4_t T[NB][NB];
   if (d == 16 * NB) {
@@ -736,8 +742,9 @@ M355_DEV void shared_factor(const double* __restrict__ src, int d, double* __res
       }
     }
   }
-  d4_t Lneg[NB][NB];  // (I > J only)
-  double mydiag = 1.0, myrinv = 1.0;
+  after_load();
+  double mydiag = 1.0;
+  M355_TICK(1);
 #pragma unroll
   for (int J = 0; J < NB; ++J) {
 #pragma unroll
@@ -749,16 +756,18 @@ M355_DEV void shared_factor(const double* __restrict__ src, int d, double* __res
     double u[16], l[16];
 #pragma unroll
     for (int c = 0; c < 16; ++c) u[c] = Pm[prow * 17 + c];
+    M355_TICK(2 + 3 * J);
+    // One wavefront, alone on its SIMD: what counts is the LATENCY of the chain pivot -> rsqrt -> l_c -> u_{c+1} ->
+    // next pivot, so the update of the next column comes first and the other 14 - c follow, free to fill the
+    // stalls of the next column's rsqrt chain (k_mvn_tiles, three wavefronts per SIMD, orders for issue instead).
 #pragma unroll
     for (int c = 0; c < 16; ++c) {
       double piv, rinv;
       sqrt_rsqrt<false>(readlane_d(u[c], 16 * J + c), piv, rinv);
       const double lc = u[c] * rinv;
       l[c] = lc;
-      if (lane == 16 * J + c) {
-        mydiag = piv;
-        myrinv = rinv;
-      }
+      rd[16 * J + c] = rinv;  // (wave-uniform value and address: one LDS write, nothing kept in registers)
+#if M355_SHARED_VARIANT == 0
 #pragma unroll
       for (int c0 = c + 1; c0 < 16; c0 += 4) {
         double m[4];
@@ -770,36 +779,67 @@ M355_DEV void shared_factor(const double* __restrict__ src, int d, double* __res
         }
         __builtin_amdgcn_sched_barrier(0);
       }
+#elif M355_SHARED_VARIANT == 1
+#pragma unroll
+      for (int c0 = c + 1; c0 < 16; c0 += 4) {
+        double m[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) m[q] = (c0 + q < 16) ? readlane_d(lc, 16 * J + (c0 + q < 16 ? c0 + q : 15)) : 0.0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          if (c0 + q < 16) u[c0 + q] = __builtin_fma(-lc, m[q], u[c0 + q]);
+        }
+      }
+#else
+      if (c + 1 < 16) u[c + 1] = __builtin_fma(-lc, readlane_d(lc, 16 * J + c + 1), u[c + 1]);
+#pragma unroll
+      for (int c0 = c + 2; c0 < 16; c0 += 4) {
+        double m[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) m[q] = (c0 + q < 16) ? readlane_d(lc, 16 * J + (c0 + q < 16 ? c0 + q : 15)) : 0.0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          if (c0 + q < 16) u[c0 + q] = __builtin_fma(-lc, m[q], u[c0 + q]);
+        }
+      }
+#endif
     }
+    M355_TICK(3 + 3 * J);
     wave_sync();
     // row layout back to LDS: lane i holds L[i][16 J + c] (rows of the diagonal block: valid for c <= i - 16 J)
 #pragma unroll
     for (int c = 0; c < 16; ++c) Pm[lane * 17 + c] = l[c];
-    if (g == J) {
+    if (g == J) {  // rows of the diagonal block, for its inverse: Dg[block][row][16] (16-byte aligned rows)
 #pragma unroll
-      for (int c = 0; c < 16; ++c) Dg[lane * 17 + c] = (c <= r16) ? l[c] : 0.0;
+      for (int c = 0; c < 16; ++c) Dg[lane * 16 + c] = (c <= r16) ? l[c] : 0.0;
     }
     wave_sync();
+    if (g == J) mydiag = Pm[lane * 17 + r16];  // L_ii = l[i - 16 J] of lane i (u_c = pivot^2 there): read back, no select chain
+
     if (J + 1 < NB) {
-      d4_t L[NB];
+      d4_t L[NB], Lneg[NB];
 #pragma unroll
       for (int I = J + 1; I < NB; ++I) {
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) L[I][kk] = Pm[(16 * I + r16) * 17 + g + 4 * kk];
-        Lneg[I][J] = -L[I];
+        Lneg[I] = -L[I];
+        // a finished tile in the A layout IS the solve's operand: published now, not carried in registers to the end
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) fr[((I * (I + 1) / 2 + J) * 4 + kk) * 64 + lane] = Lneg[I][kk];
       }
 #pragma unroll
       for (int K = J + 1; K < NB; ++K) {
 #pragma unroll
         for (int I = K; I < NB; ++I) {
 #pragma unroll
-          for (int kk = 0; kk < 4; ++kk) T[I][K] = __builtin_amdgcn_mfma_f64_16x16x4f64(Lneg[K][J][kk], L[I][kk], T[I][K], 0, 0, 0);
+          for (int kk = 0; kk < 4; ++kk) T[I][K] = __builtin_amdgcn_mfma_f64_16x16x4f64(Lneg[K][kk], L[I][kk], T[I][K], 0, 0, 0);
         }
       }
       wave_sync();
     }
+    M355_TICK(4 + 3 * J);
   }
-  if (lane < 16 * NB) rd[lane] = myrinv;
+  M355_TICK(20);
   {
     double lg = flog(mydiag);  // identity padding: log 1 = 0; a NaN pivot -> NaN
 #pragma unroll
@@ -810,34 +850,41 @@ M355_DEV void shared_factor(const double* __restrict__ src, int d, double* __res
   // inverse of the diagonal blocks: lane (block g, column r16) runs one forward substitution on e_c
   //   X[c][c] = 1 / L[c][c],  X[r][c] = -(sum_{k=c}^{r-1} L[r][k] X[k][c]) / L[r][r]
   {
+    // (x[k] = 0 for k < c by construction, so the sums need no select; the rows of L arrive by 16-byte broadcast reads
+    // that do not depend on x: the chain is one multiply-add and one multiply per row)
     const int blk = g < NB ? g : NB - 1, c = r16;
-    const double* Lb = Dg + (16 * blk) * 17;
+    const d2_t* Lb = reinterpret_cast<const d2_t*>(Dg + (16 * blk) * 16);
     const double* rdb = rd + 16 * blk;
     double x[16];
+    int dep = 0;  // always 0: see below
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       double acc = 0.0;
 #pragma unroll
-      for (int k = 0; k < r; ++k) acc = __builtin_fma(Lb[r * 17 + k], (k >= c) ? x[k] : 0.0, acc);
-      x[r] = (r == c) ? rdb[r] : (r > c ? -acc * rdb[r] : 0.0);
+      for (int k2 = 0; 2 * k2 < r; ++k2) {
+        const d2_t lv = Lb[r * 8 + k2 + dep];
+        acc = __builtin_fma(lv.x, x[2 * k2], acc);
+        if (2 * k2 + 1 < r) acc = __builtin_fma(lv.y, x[2 * k2 + 1], acc);
+      }
+      const double rdr = rdb[r];
+      x[r] = (r == c) ? rdr : (r > c ? -acc * rdr : 0.0);
+      // The reads do not depend on x: left alone the compiler issues all 64 of them (256 VGPRs: spills) in front of the
+      // chain, and neither fences nor scheduling barriers held it back.  Every fourth row the (zero) offset of the
+      // next rows' reads passes through an empty asm together with x[r], which makes them wait for it: at most ~30 reads in flight.
+      if ((r & 3) == 3) asm volatile("" : "+v"(dep), "+v"(x[r]));
     }
     wave_sync();
-    if (g < NB) {
+    if (g < NB) {  // X back to LDS, row-major with the odd stride of Pm (read below in the A layout)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) Dg[(16 * blk + r) * 17 + c] = x[r];
+      for (int r = 0; r < 16; ++r) Pm[(16 * blk + r) * 17 + c] = x[r];
     }
     wave_sync();
   }
+  M355_TICK(21);
 #pragma unroll
   for (int I = 0; I < NB; ++I) {
 #pragma unroll
-    for (int J = 0; J <= I; ++J) {
-#pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
-        const double v = (J == I) ? Dg[(16 * I + r16) * 17 + g + 4 * kk] : Lneg[I][J][kk];
-        fr[((I * (I + 1) / 2 + J) * 4 + kk) * 64 + lane] = v;
-      }
-    }
+    for (int kk = 0; kk < 4; ++kk) fr[((I * (I + 1) / 2 + I) * 4 + kk) * 64 + lane] = Pm[(16 * I + r16) * 17 + g + 4 * kk];
   }
 }
 
@@ -846,9 +893,9 @@ __global__ __launch_bounds__(64 * kSharedWaves) void k_mvn_shared(const double* 
   constexpr int NBLK = NB * (NB + 1) / 2;
   constexpr int S = 16 * NB + 4;  // staging row stride (as k_solve_mfma)
   constexpr int NJ = 2 * NB;      // 16-byte loads per lane per tile
-  extern __shared__ double lds[];
-  double* Pm = lds;                     // 64 x 17: wavefront 0's panel buffer (row layout)
-  double* Dg = Pm + 64 * 17;            // 64 x 17: rows of the diagonal blocks, then their inverses
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  double* Pm = lds;                     // 64 x 17: wavefront 0's panel buffer (row layout), then the inverses of the diagonal blocks
+  double* Dg = Pm + 64 * 17;            // 64 x 16 (+ padding): rows of the diagonal blocks
   double* rd = Dg + 64 * 17;            // 64: 1 / L_ii
   double* fr = rd + 64;                 // NBLK x 4 x 64 operands of the solve
   double* misc = fr + NBLK * 256;       // [0] logdet
@@ -881,15 +928,9 @@ __global__ __launch_bounds__(64 * kSharedWaves) void k_mvn_shared(const double* 
     }
   };
   long long tile = (long long)blockIdx.x * kSharedWaves + wave;
-  if (tile < ntiles) fetch(tile);  // in flight during the factorisation
-  for (int e = threadIdx.x; e < 16 * NB; e += blockDim.x) mu_s[e] = (!MU_ROWS && e < d) ? a.mu[e] : 0.0;
+  // (the mean is fetched by the LAST wavefront: wavefront 0's first memory operations are the loads of the covariance)
+  if (wave == kSharedWaves - 1 && lane < 16 * NB) mu_s[lane] = (!MU_ROWS && lane < d) ? a.mu[lane] : 0.0;
   for (int e = lane; e < 16 * S; e += 64) st[e] = 0.0;  // padding columns stay zero for the whole kernel
-  if (wave == 0) shared_factor<NB>(cov, d, Pm, Dg, rd, fr, misc);  // (wave-uniform branch; no workgroup barrier inside)
-  __syncthreads();
-  double F[NBLK * 4];
-#pragma unroll
-  for (int b = 0; b < NBLK * 4; ++b) F[b] = fr[b * 64 + lane];
-  const double logdet = misc[0];
   int off0[NJ], off1[NJ];
   const float invd = 1.0f / (float)d;
 #pragma unroll
@@ -900,14 +941,39 @@ __global__ __launch_bounds__(64 * kSharedWaves) void k_mvn_shared(const double* 
     off0[j] = e < tile_elems ? o0 * S + c0 : -1;
     off1[j] = (e + 1) < tile_elems ? o1 * S + c1 : -1;
   }
-  const int rbase = (lane & 15) * S + (lane >> 4);
-  for (; tile < ntiles; tile += gstride) {
+  auto stage = [&]() {
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
       if (off0[j] >= 0) st[off0[j]] = raw[j].x;
       if (off1[j] >= 0) st[off1[j]] = raw[j].y;
     }
-    if (tile + gstride < ntiles) fetch(tile + gstride);  // in flight during the MFMA chain below
+  };
+  // the first tile goes to the staging buffer BEFORE the factorisation (wavefront 0: behind the loads of the covariance):
+  // the load overlaps it, and no observation registers are live while wavefront 0 needs them all
+  __builtin_amdgcn_wave_barrier();
+  if (wave != 0 && tile < ntiles) {
+    fetch(tile);
+    stage();
+  }
+  if (wave == 0) {  // (wave-uniform branch; no workgroup barrier inside)
+    shared_factor<NB>(cov, d, Pm, Dg, rd, fr, misc, [&]() {
+      if (tile < ntiles) {
+        fetch(tile);
+        stage();
+      }
+    });
+  }
+  M355_TICK(22);
+  __syncthreads();
+  M355_TICK(23);
+  double F[NBLK * 4];
+#pragma unroll
+  for (int b = 0; b < NBLK * 4; ++b) F[b] = fr[b * 64 + lane];
+  const double logdet = misc[0];
+  const int rbase = (lane & 15) * S + (lane >> 4);
+  for (; tile < ntiles; tile += gstride) {
+    const bool more = tile + gstride < ntiles;
+    if (more) fetch(tile + gstride);  // in flight during the MFMA chain below
     __builtin_amdgcn_wave_barrier();
     double quad = 0.0;
     d4_t Y[NB];
@@ -941,6 +1007,7 @@ __global__ __launch_bounds__(64 * kSharedWaves) void k_mvn_shared(const double* 
       }
       a.out[r] = v;
     }
+    if (more) stage();  // (after this tile's reads of the buffer: one wavefront, program order)
   }
 }
 

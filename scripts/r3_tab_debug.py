@@ -58,3 +58,17 @@ for name, chunk in (("beta", 0), ("beta", 1), ("beta", 3)):
                 if b.any():
                     i = np.where(b)[0][:3]
                     print(name, params, fn, label, int(b.sum()), "pts", pts[i], "tab", tab[i], "exact", exact[i], "oracle", exp[i], flush=True)
+
+# 3. beta(0.5, 499.5) logsf around x = 8e-7: table vs exact vs oracle on a dense grid
+print("---- beta(0.5, 499.5) logsf dense grid")
+xs = np.exp(np.linspace(np.log(2e-7), np.log(4e-6), 4000))
+tab, exact, exp = both("beta", "logsf", xs, (0.5, 499.5))
+d = np.abs(tab - exact)
+import mpmath as mp
+mp.mp.dps = 40
+for i in np.argsort(-d)[:5]:
+    ref = mp.log(mp.betainc(499.5, 0.5, 0, 1 - mp.mpf(xs[i]), regularized=True))
+    print("x", xs[i], "tab", tab[i], "exact", exact[i], "oracle", exp[i], "mp(true, smooth)", float(ref), "tab-exact", tab[i] - exact[i])
+print("fraction tab != exact", np.mean(tab != exact), "max diff", d.max(), "count > 5e-13", int((d > 5e-13).sum()))
+blocks = np.array_split(np.arange(xs.size), 40)
+print("per block max |tab-exact| and miss fraction:", [(f"{xs[b[0]]:.2e}", f"{d[b].max():.1e}", round(float(np.mean(tab[b] == exact[b])), 2)) for b in blocks])

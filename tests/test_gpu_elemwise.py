@@ -443,9 +443,9 @@ def test_tabulated_kernel(gpu, name, params):
         tabulated = 1.0 <= params[0] <= 50.0
     else:
         tabulated = min(params) >= 0.01 and sum(params) <= 500.0
-    # quantiles: gamma from alpha = 0.05, beta from a = 0.05 with b >= 1 (shapes below 1 as tables of log(ppf): tab_ppf_log)
+    # quantiles: gamma from alpha = 0.05, beta from a = 0.1 with b >= 1 (shapes below 1 as tables of log(ppf): tab_ppf_log)
     tabulated_q = tabulated and (name in ("studentt", "halfstudentt") or (name == "gamma" and params[0] >= 0.05) or
-                                 (name == "beta" and params[0] >= 0.05 and params[1] >= 1.0))
+                                 (name == "beta" and params[0] >= 0.1 and params[1] >= 1.0))
     tabulated_all = tabulated
     for fn in ("logcdf", "logsf", "cdf", "sf"):
         # (beta.logsf / sf with alpha < 1/2 are left to the exact kernels: Dist<M355_BETA>::tab_ok_fn)
