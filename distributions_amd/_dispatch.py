@@ -161,16 +161,22 @@ _TABLE_WS_MAX = 1 << 30
 def _table_workspace(dist: str, fn: str, pl: Plan, torch, device):
     """Scratch for m355_elemwise_ws, from torch's caching allocator (a per-call block: calls on different streams never
     share one), or None where no table can apply."""
-    if dist not in TABLE_DISTS or fn in ("logpdf", "pdf") or pl.operands[0].kind != "full":
+    if pl.operands[0].kind != "full":
         return None
     period = 0
     for op in pl.operands[1:]:
         if op.kind == "scalar":
             continue
-        if op.div != 1 or (period and op.mod != period):
+        if op.div != 1 or (period and op.mod != period) or op.mod >= pl.n:
             return None  # not row-periodic: the library's generic kernel
         period = int(op.mod)
-    need = int(_lib.lib().m355_elemwise_workspace_bytes_for(pl.n, period))
+    densities = fn in ("logpdf", "pdf")
+    if period == 0 and (densities or dist not in TABLE_DISTS):
+        return None
+    if period and (densities or dist not in TABLE_DISTS):
+        need = period * 16 * 8  # the derived constants of the P parameter sets (k_periodic_fixed)
+    else:
+        need = int(_lib.lib().m355_elemwise_workspace_bytes_for(pl.n, period))
     if need == 0 or need > _TABLE_WS_MAX:
         return None
     return torch.empty(need, dtype=torch.uint8, device=device)

@@ -147,8 +147,14 @@ size_t m355_elemwise_workspace_bytes(void) { return (size_t)32 << 20; }
 size_t m355_elemwise_workspace_bytes_for(int64_t n, int64_t period) {
   if (n <= 0 || period < 0) return 0;
   if (period == 0) return (size_t)m355::kTabDoubles * sizeof(double);
-  if (period % m355::kCtCols != 0) return 0;  // no per-column tables for this period
-  return m355::coltab_ws_doubles<M355_LOGCDF>((unsigned long long)period, (long long)(n / period)) * sizeof(double);
+  // the derived constants of the P parameter sets (k_periodic_fixed: stored logpdf / pdf), and, for periods the table
+  // kernels take, the per-column tables and miss words of logcdf / logsf / cdf / sf / ppf / isf
+  size_t need = (size_t)period * 16 * sizeof(double);
+  if (period % m355::kCtCols == 0) {
+    const size_t t = m355::coltab_ws_doubles<M355_LOGCDF>((unsigned long long)period, (long long)(n / period)) * sizeof(double);
+    need = t > need ? t : need;
+  }
+  return need;
 }
 
 int m355_elemwise_ws(int dist, int fn, int out_dtype, int64_t n, const m355_operand* x, int nparams,

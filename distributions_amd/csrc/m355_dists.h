@@ -284,6 +284,15 @@ template <> struct Dist<M355_BETA> {
     if (FN == M355_LOGSF || FN == M355_SF) return k.a >= 0.5;
     return true;
   }
+  // betainc's own rounding noise grows with the shapes (the prefactor x^a y^b / B carries ~1e-16 (a + b)): 9e-14 at
+  // (150, 300) against the node function itself (tests/hostmath hm_tab_build2) -- with four dropped coefficients as the
+  // measure (round 3) 69 % of that table's cells failed 1e-14.  2.5e-16 (a + b) from a + b = 40: 1.1e-13 at 450, which
+  // keeps |table - exact kernel| below 3e-13 and both inside the 1e-12 bar.
+  // (only with both shapes >= 1: below, logsf follows the reference's staircase -- betainc at the rounded 1 - x -- whose
+  // cells must go on failing at 1e-14; at (0.5, 499.5) the looser tolerance let a cell pass that sat 6e-13 off it)
+  static M355_HD double tab_tol(const K& k) {
+    return 1e-14 * ((k.a >= 1.0 && k.b >= 1.0 && k.a + k.b > 40.0) ? (k.a + k.b) * (1.0 / 40.0) : 1.0);
+  }
   static M355_HD bool tab_warped(const K& k) { return (k.a < 1.0) | (k.b < 1.0); }
   // beta.py:66-67 cdf = exp(logcdf); beta.py:82-83 sf = exp(logsf)
   template <int FN> static constexpr TabRoute tab_route() {

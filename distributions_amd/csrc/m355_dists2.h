@@ -896,6 +896,7 @@ template <> struct Dist<M355_BETASCALED> {
   }
   // k_tab: logit of the position in (lower, upper), both differences formed from x directly (conditions as for beta)
   static M355_HD bool tab_ok(const K& k) { return k.a >= 1.0 && k.b >= 1.0 && k.a + k.b <= 500.0 && k.w > 0.0 && k.w < kInf; }
+  static M355_HD double tab_tol(const K& k) { return 1e-14 * (k.a + k.b > 40.0 ? (k.a + k.b) * (1.0 / 40.0) : 1.0); }  // (as Dist<M355_BETA>)
   // betascaled.py:71-72 cdf = exp(logcdf); betascaled.py:88-89 sf = 1 - cdf
   template <int FN> static constexpr TabRoute tab_route() {
     return FN == M355_CDF ? TabRoute{M355_LOGCDF, kTabEpiExp} : TabRoute{M355_LOGCDF, kTabEpiOneMinusExp};

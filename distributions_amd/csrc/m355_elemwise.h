@@ -475,6 +475,58 @@ __global__ __launch_bounds__(kBlock) void k_periodic_prod(const void* __restrict
   if (threadIdx.x == 0) partials[blockIdx.x] = acc;
 }
 
+// Stored results with row-periodic parameters, the same way: when the caller brings a workspace (m355_elemwise_ws),
+// k_derive_table writes the P derived constant sets to it once and k_periodic_fixed streams x with no LDS table -- the
+// launcher makes gridDim.x * kTile a multiple of P, so a thread meets the same kUnroll * kVec columns in every tile and
+// reads their constants once (L2).  k_periodic's table (48 KiB for beta at P = 1024) allowed two or three workgroups per
+// CU and every workgroup repeated the P lgamma / log derivations: stored logpdf ran at 48-57 % of HBM where scalar
+// parameters reach 77 %.
+template <int D, int FN, bool F64IO>
+__global__ __launch_bounds__(kBlock) void k_periodic_fixed(const void* __restrict__ x, int xdt, void* __restrict__ out, int odt,
+                                                           long long n, unsigned P, const double* __restrict__ table) {
+  constexpr int IO = F64IO ? 1 : 0;
+  using DD = Dist<D>;
+  using K = typename DD::K;
+  constexpr int NK = sizeof(K) / sizeof(double);
+  if constexpr (uses_log_table<DD>::value) log_table_init();
+  auto fetch = [&](unsigned idx) {
+    K k;
+    double* kd = reinterpret_cast<double*>(&k);
+#pragma unroll
+    for (int f = 0; f < NK; ++f) kd[f] = table[(size_t)f * P + idx];
+    return k;
+  };
+  const long long ntiles = n / kTile;
+  K kc[kUnroll][kVec];
+  {
+    unsigned idx = (unsigned)(((unsigned long long)blockIdx.x * kTile + threadIdx.x * kVec) % P);
+    const unsigned u_step = (unsigned)((kBlock * kVec) % P);
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) {
+      unsigned idx1 = idx + 1;
+      idx1 = idx1 >= P ? idx1 - P : idx1;
+      kc[u][0] = fetch(idx);
+      kc[u][1] = fetch(idx1);
+      idx += u_step;
+      idx = idx >= P ? idx - P : idx;
+    }
+  }
+  for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const long long base = tile * kTile + threadIdx.x * kVec;
+    double v[kUnroll][kVec];
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) load2<IO>(x, xdt, base + u * (kBlock * kVec), v[u][0], v[u][1]);
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) {
+      v[u][0] = DD::template eval<FN>(v[u][0], kc[u][0]);
+      v[u][1] = DD::template eval<FN>(v[u][1], kc[u][1]);
+      store2<IO>(out, odt, base + u * (kBlock * kVec), v[u][0], v[u][1]);
+    }
+  }
+  for (long long i = ntiles * kTile + (long long)blockIdx.x * kBlock + threadIdx.x; i < n; i += (long long)gridDim.x * kBlock)
+    store1(out, odt, i, DD::template eval<FN>(load1(x, xdt, i), fetch((unsigned)((unsigned long long)i % P))));
+}
+
 // ------------------------------------------------------------------------------------------------
 // k_binned: the special-function kernels (logcdf / logsf / ppf of gamma, beta, studentt, ...) are pinned at the
 // VALU issue limit with lane_util 0.25-0.5: lanes of a wavefront run series / continued fractions / Newton loops
@@ -816,10 +868,12 @@ template <class T, int FN> constexpr bool bin_this() {
 // (m355_elemwise_ws, include/m355_dist.h); the evaluation kernel copies the finished table (20 KiB) into LDS:
 //   * kTabCells = 256 cells across [ppf(1e-9), ppf(1 - 1e-9)] in a variable w = Dist<>::tab_w(x) in which the function is
 //     tame (log x for gamma, logit x for beta, asinh z for studentt; logit q for the quantiles);
-//   * per cell a Chebyshev interpolant from kTabNodes = 12 exact evaluations at the cell's Chebyshev nodes, of which the
-//     first kTabCoef = 10 coefficients are kept (degree 9): the two that are dropped MEASURE what the truncation loses --
-//     and any noise in the node values (a badly conditioned x(w), the exact body's own rounding at large parameters) --
-//     so a cell is used only if |c_10| + |c_11| <= 1e-14 of its scale; a cell that fails is poisoned with NaN;
+//   * per cell a Chebyshev interpolant from kTabNodes = 14 exact evaluations at the cell's Chebyshev nodes, of which the
+//     first kTabCoef = 10 coefficients are kept (degree 9): the four that are dropped MEASURE what the truncation loses --
+//     and any noise in the node values (a badly conditioned x(w), the exact body's own rounding at large parameters, a
+//     staircase in the reference's own formula) -- so a cell is used only if |c_10| + ... + |c_13| <= 1e-14 of its scale;
+//     a cell that fails is poisoned with NaN.  (Four, not two: with two, one noisy cell in ~2000 passes by chance -- round
+//     3's sweep of the acceptance boxes met one at beta(0.5, 499.5).logsf, 1.5e-12 off the reference's staircase);
 //   * the kept coefficients are converted to the monomial basis in the cell's t in [-1, 1) (safe: a validated cell's
 //     coefficients fall by >= 25x per degree), ten doubles = 80 bytes per cell: a lookup is one table logarithm, the cell
 //     arithmetic, FIVE 16-byte LDS reads and a degree-9 Horner chain.  (Round 2 built a 64 x degree-15 table in every
@@ -828,7 +882,7 @@ template <class T, int FN> constexpr bool bin_this() {
 // An element whose lookup is NaN -- poisoned cell, w outside the table, NaN / out-of-support argument -- takes the exact
 // body.  So the table can only replace the exact value where it has shown itself converged; the price of a miss is
 // divergence.
-constexpr int kTabCells = 256, kTabNodes = 12, kTabCoef = 10, kTabStride = 10, kTabHdr = 8;
+constexpr int kTabCells = 256, kTabNodes = 14, kTabCoef = 10, kTabStride = 10, kTabHdr = 8;
 constexpr int kTabDoubles = kTabHdr + kTabCells * kTabStride;  // header: [0] w_lo, [1] cells per unit of w (NaN: no table)
 constexpr int kTabBuildWaves = kTabCells / 4;                   // k_tab_build: one wavefront (= workgroup) per four cells
 constexpr double kTabTailQ = 1e-9;     // the table spans the quantiles [kTabTailQ, 1 - kTabTailQ]
@@ -864,6 +918,15 @@ template <class DD> M355_DEV double tab_logit(double qq) {
 // noise, e.g. log of a difference of O(1) numbers): a miss, i.e. the exact body's reproduction of that arithmetic
 template <class T, class = void> struct has_tab_value_miss : std::false_type {};
 template <class T> struct has_tab_value_miss<T, std::void_t<decltype(&T::template tab_value_miss<M355_LOGCDF>)>> : std::true_type {};
+// Dist<>::tab_tol(k): the validation tolerance where the exact body's own rounding noise exceeds 1e-14 inside the box
+// tab_ok accepts (beta at a + b in the hundreds): a table cannot show itself closer to its nodes than the nodes are to
+// each other
+template <class T, class = void> struct has_tab_tol : std::false_type {};
+template <class T> struct has_tab_tol<T, std::void_t<decltype(&T::tab_tol)>> : std::true_type {};
+template <class DD> M355_DEV double tab_tol_of(const typename DD::K& k) {
+  if constexpr (has_tab_tol<DD>::value) return DD::tab_tol(k);
+  else return kTabCoefTol;
+}
 template <class T, class = void> struct has_tab_cap : std::false_type {};
 template <class T> struct has_tab_cap<T, std::void_t<decltype(&T::tab_cap)>> : std::true_type {};
 template <class T, class = void> struct has_tab_fnode : std::false_type {};
@@ -891,19 +954,21 @@ template <class DD, int FN> constexpr bool tab_this() {
 // tail.  isf(q) is the reference's ppf(1 - q) with the rounded 1 - q (e.g. gamma.py:57-58), so it looks up
 // qq = fl(1 - q) -- the same staircase as the exact kernel.
 constexpr double kTabLogitMax = 20.723265835946928;  // logit(1 - 1e-9)
-// cos(pi a / 24), a = 0 .. 47: the 12 Chebyshev nodes of a k_tab cell are the odd entries below 24, and
-// cos(pi m (2 q + 1) / 24) = entry m (2 q + 1) mod 48
-constexpr double kCos24[48] = {
-    0x1.0000000000000p+0, 0x1.fb9ea92ec689bp-1, 0x1.ee8dd4748bf15p-1, 0x1.d906bcf328d46p-1, 0x1.bb67ae8584caap-1,
-    0x1.963268b572492p-1, 0x1.6a09e667f3bcdp-1, 0x1.37af93f9513eap-1, 0x1.0000000000000p-1, 0x1.87de2a6aea963p-2,
-    0x1.0907dc1930690p-2, 0x1.0b5150f6da2d1p-3, 0.0, -0x1.0b5150f6da2d1p-3, -0x1.0907dc1930690p-2, -0x1.87de2a6aea963p-2,
-    -0x1.0000000000000p-1, -0x1.37af93f9513eap-1, -0x1.6a09e667f3bcdp-1, -0x1.963268b572492p-1, -0x1.bb67ae8584caap-1,
-    -0x1.d906bcf328d46p-1, -0x1.ee8dd4748bf15p-1, -0x1.fb9ea92ec689bp-1, -0x1.0000000000000p+0, -0x1.fb9ea92ec689bp-1,
-    -0x1.ee8dd4748bf15p-1, -0x1.d906bcf328d46p-1, -0x1.bb67ae8584caap-1, -0x1.963268b572492p-1, -0x1.6a09e667f3bcdp-1,
-    -0x1.37af93f9513eap-1, -0x1.0000000000000p-1, -0x1.87de2a6aea963p-2, -0x1.0907dc1930690p-2, -0x1.0b5150f6da2d1p-3,
-    0.0, 0x1.0b5150f6da2d1p-3, 0x1.0907dc1930690p-2, 0x1.87de2a6aea963p-2, 0x1.0000000000000p-1, 0x1.37af93f9513eap-1,
-    0x1.6a09e667f3bcdp-1, 0x1.963268b572492p-1, 0x1.bb67ae8584caap-1, 0x1.d906bcf328d46p-1, 0x1.ee8dd4748bf15p-1,
-    0x1.fb9ea92ec689bp-1};
+// cos(pi a / 28), a = 0 .. 55: the 14 Chebyshev nodes of a k_tab cell are the odd entries below 28, and
+// cos(pi m (2 q + 1) / 28) = entry m (2 q + 1) mod 56
+constexpr double kCos28[56] = {
+    0x1.0000000000000p+0, 0x1.fcc7d8c64135fp-1, 0x1.f329c0558e969p-1, 0x1.e344ad05d3f86p-1, 0x1.cd4bca9cb5c71p-1,
+    0x1.b185d590d5a44p-1, 0x1.904c37505de4bp-1, 0x1.6a09e667f3bcdp-1, 0x1.3f3a0e28bedd1p-1, 0x1.106682221cd8ap-1,
+    0x1.bc4c04d71abc1p-2, 0x1.5234aca69a9fep-2, 0x1.c7b90e3024582p-3, 0x1.ca9b4332d6f61p-4, 0.0,
+    -0x1.ca9b4332d6f61p-4, -0x1.c7b90e3024582p-3, -0x1.5234aca69a9fep-2, -0x1.bc4c04d71abc1p-2, -0x1.106682221cd8ap-1,
+    -0x1.3f3a0e28bedd1p-1, -0x1.6a09e667f3bcdp-1, -0x1.904c37505de4bp-1, -0x1.b185d590d5a44p-1, -0x1.cd4bca9cb5c71p-1,
+    -0x1.e344ad05d3f86p-1, -0x1.f329c0558e969p-1, -0x1.fcc7d8c64135fp-1, -0x1.0000000000000p+0, -0x1.fcc7d8c64135fp-1,
+    -0x1.f329c0558e969p-1, -0x1.e344ad05d3f86p-1, -0x1.cd4bca9cb5c71p-1, -0x1.b185d590d5a44p-1, -0x1.904c37505de4bp-1,
+    -0x1.6a09e667f3bcdp-1, -0x1.3f3a0e28bedd1p-1, -0x1.106682221cd8ap-1, -0x1.bc4c04d71abc1p-2, -0x1.5234aca69a9fep-2,
+    -0x1.c7b90e3024582p-3, -0x1.ca9b4332d6f61p-4, 0.0, 0x1.ca9b4332d6f61p-4, 0x1.c7b90e3024582p-3,
+    0x1.5234aca69a9fep-2, 0x1.bc4c04d71abc1p-2, 0x1.106682221cd8ap-1, 0x1.3f3a0e28bedd1p-1, 0x1.6a09e667f3bcdp-1,
+    0x1.904c37505de4bp-1, 0x1.b185d590d5a44p-1, 0x1.cd4bca9cb5c71p-1, 0x1.e344ad05d3f86p-1, 0x1.f329c0558e969p-1,
+    0x1.fcc7d8c64135fp-1};
 // cos(pi a / 32), a = 0 .. 63: the same for the 16-node cells of k_coltab
 constexpr double kCos32[64] = {
     0x1.0000000000000p+0, 0x1.fd88da3d12526p-1, 0x1.f6297cff75cb0p-1, 0x1.e9f4156c62ddap-1,
@@ -956,6 +1021,8 @@ template <class DD, int FN> M355_DEV double tab_node_value(double w, const typen
         const double lsf = DD::template eval<M355_LOGSF>(f, k);
         const double step = (lsf - lp) * exp_(lsf - DD::template eval<M355_LOGPDF>(f, k));
         if (step - step == 0.0) f += step;
+        // (Newton squares the error: a first step below 1e-9 of the root leaves < 1e-17 for the second)
+        if (__builtin_fabs(step) <= 1e-9 * __builtin_fabs(f)) break;
       }
     }
     if (tab_log_mode<DD, FN>(k)) f = flog(f);
@@ -981,7 +1048,7 @@ template <int D, int FN> __device__ __noinline__ double tab_exact(double x, cons
   return Dist<D>::template eval<FN>(x, k);
 }
 
-// One wavefront per four cells: lane = 16 * (cell in the group) + node; lanes 12 .. 15 of a cell repeat node 11.
+// One wavefront per four cells: lane = 16 * (cell in the group) + node; lanes 14, 15 of a cell repeat node 13.
 template <int D, int FN>
 __global__ __launch_bounds__(64) void k_tab_build(const typename Dist<D>::K k, double* __restrict__ table) {
   using DD = Dist<D>;
@@ -1000,15 +1067,15 @@ __global__ __launch_bounds__(64) void k_tab_build(const typename Dist<D>::K k, d
   const double h = (whi - wlo) * (1.0 / kTabCells);
   const int cell = blockIdx.x * 4 + cl;
   const int jn = m < kTabNodes ? m : kTabNodes - 1;
-  const double w = wlo + h * ((double)cell + 0.5 + 0.5 * kCos24[2 * jn + 1]);
+  const double w = wlo + h * ((double)cell + 0.5 + 0.5 * kCos28[2 * jn + 1]);
   fv[lane] = (h > 0.0) ? tab_node_value<DD, RT.fn>(w, k) : kNaN;  // (an empty or NaN range: no table, see the header)
   __syncthreads();
-  // Chebyshev coefficients: c_m = (2 / 12) sum_j f_j cos(pi m (j + 1/2) / 12), c_0 halved
+  // Chebyshev coefficients: c_m = (2 / 14) sum_j f_j cos(pi m (j + 1/2) / 14), c_0 halved
   double c = 0.0;
   if (m < kTabNodes) {
     double acc = 0.0;
 #pragma unroll
-    for (int q = 0; q < kTabNodes; ++q) acc = __builtin_fma(fv[cl * 16 + q], kCos24[(m * (2 * q + 1)) % 48], acc);
+    for (int q = 0; q < kTabNodes; ++q) acc = __builtin_fma(fv[cl * 16 + q], kCos28[(m * (2 * q + 1)) % 56], acc);
     c = acc * (m == 0 ? 1.0 / kTabNodes : 2.0 / kTabNodes);
   }
   // the parity bar is relative to max(1, |value|); a quantile must hold it relative to the root itself (sum |c_k| >= the
@@ -1021,7 +1088,7 @@ __global__ __launch_bounds__(64) void k_tab_build(const typename Dist<D>::K k, d
     tail += __shfl_xor(tail, o, 16);
   }
   const double scale = ((QDOM && !tab_log_mode<DD, FN>(k)) || sum > 1.0) ? sum : 1.0;
-  const bool bad = !(tail <= kTabCoefTol * scale);  // NaN / inf coefficients are bad too
+  const bool bad = !(tail <= tab_tol_of<DD>(k) * scale);  // NaN / inf coefficients are bad too
   __syncthreads();
   fv[lane] = c;
   __syncthreads();
@@ -1157,8 +1224,12 @@ constexpr int kCtCols = 16, kCtThreads = 1024, kCtRows = kCtThreads / kCtCols;  
 #define M355_CT_UNROLL_CDF 2
 #endif
 template <int FN> constexpr int ct_unroll() { return (FN == M355_PPF || FN == M355_ISF) ? 4 : M355_CT_UNROLL_CDF; }
-template <int FN> constexpr int ct_iters() { return 64 / ct_unroll<FN>(); }                    // passes per chunk: one miss bit per element
-template <int FN> constexpr int ct_chunk_rows() { return ct_iters<FN>() * ct_unroll<FN>() * kCtRows; }  // 4096
+// rows per thread and pass whose loads are issued together (k_coltab is a stream: with two 8-byte loads per lane in
+// flight, 16 wavefronts per CU held 16 KiB of reads in the air and the kernel ran at the 3 TB/s that buys; eight loads
+// per lane quadruple it); the lookups then go in groups of ct_unroll
+constexpr int kCtLoad = 8;
+template <int FN> constexpr int ct_iters() { return 64 / kCtLoad; }                    // passes per chunk: one miss bit per element
+template <int FN> constexpr int ct_chunk_rows() { return ct_iters<FN>() * kCtLoad * kCtRows; }  // 4096
 constexpr size_t kCtLds = (size_t)kCtCols * kCtTable * sizeof(double);  // dynamic LDS: 117760 B
 // workspace: P tables | G chunk counters (+ padding to 8 bytes) | one miss word per (group, chunk, thread) = n / 64 words
 template <int FN> inline size_t coltab_chunks(long long R) { return (size_t)((R + ct_chunk_rows<FN>() - 1) / ct_chunk_rows<FN>()); }
@@ -1252,7 +1323,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(min_wave
     tail += __shfl_xor(tail, o, 16);
   }
   const double scale = ((QDOM && !tab_log_mode<DD, FN>(k)) || sum > 1.0) ? sum : 1.0;
-  const bool bad = !(tail <= kTabCoefTol * scale);
+  const bool bad = !(tail <= tab_tol_of<DD>(k) * scale);
   __syncthreads();
   fv[t] = c;
   __syncthreads();
@@ -1347,31 +1418,39 @@ __global__ __launch_bounds__(kCtThreads) void k_coltab(const void* __restrict__ 
       unsigned long long missed = 0;
 #pragma unroll 1
       for (int it = 0; it < ct_iters<FN>(); ++it) {
-        const long long rowb = row0 + (long long)it * (U * kCtRows);          // uniform
+        const long long rowb = row0 + (long long)it * (kCtLoad * kCtRows);     // uniform
         if (rowb >= R) break;
         const long long ubase = rowb * (long long)P + (long long)g * kCtCols;  // uniform
         const long long rows_left = R - rowb;                                  // uniform
-        double v[U], r[U];
+        double v[kCtLoad];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
+        for (int u = 0; u < kCtLoad; ++u) {
           const long long ub = ubase + (long long)(u * kCtRows) * (long long)P;
           const bool live = (rloc < rows_left - u * kCtRows) & !declined;
           if constexpr (F64IO) v[u] = live ? __builtin_nontemporal_load((const double*)x + ub + lane_off) : 0.0;
           else v[u] = live ? load1(x, xdt, (unsigned long long)(ub + lane_off)) : 0.0;
         }
 #pragma unroll
-        for (int u = 0; u < U; ++u) r[u] = lookup(v[u]);
+        for (int b = 0; b < kCtLoad; b += U) {
+          double r[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-          const long long ub = ubase + (long long)(u * kCtRows) * (long long)P;
-          const bool live = (rloc < rows_left - u * kCtRows) & !declined;
-          const bool hit = r[u] == r[u];
-          if constexpr (F64IO) {
-            if (live & hit) __builtin_nontemporal_store(r[u], (double*)out + ub + lane_off);
-          } else {
-            if (live & hit) store1(out, odt, ub + lane_off, r[u]);
+#ifdef M355_CT_COPY  // (probe: the access pattern alone)
+          for (int u = 0; u < U; ++u) r[u] = v[b + u] + wlo;
+#else
+          for (int u = 0; u < U; ++u) r[u] = lookup(v[b + u]);
+#endif
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            const long long ub = ubase + (long long)((b + u) * kCtRows) * (long long)P;
+            const bool live = (rloc < rows_left - (b + u) * kCtRows) & !declined;
+            const bool hit = r[u] == r[u];
+            if constexpr (F64IO) {
+              if (live & hit) __builtin_nontemporal_store(r[u], (double*)out + ub + lane_off);
+            } else {
+              if (live & hit) store1(out, odt, ub + lane_off, r[u]);
+            }
+            missed |= (unsigned long long)(live & !hit) << (it * kCtLoad + b + u);
           }
-          missed |= (unsigned long long)(live & !hit) << (it * U + u);
         }
       }
       miss_words[((size_t)g * chunks + ch) * kCtThreads + t] = missed;
@@ -1387,7 +1466,6 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(min_wave
     const unsigned long long* __restrict__ miss_words, unsigned long long nwords) {
   using DD = Dist<D>;
   using K = typename DD::K;
-  constexpr int U = ct_unroll<FN>();
   log_table_init();
   const unsigned chunks = (unsigned)((R + ct_chunk_rows<FN>() - 1) / ct_chunk_rows<FN>());
   for (unsigned long long w = (unsigned long long)blockIdx.x * kBlock + threadIdx.x; w < nwords; w += (unsigned long long)gridDim.x * kBlock) {
@@ -1405,7 +1483,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(min_wave
     while (mask) {
       const int b = __builtin_ctzll(mask);
       mask &= mask - 1;
-      const long long row = row0 + (long long)(b / U) * (U * kCtRows) + (long long)(b % U) * kCtRows + rloc;
+      const long long row = row0 + (long long)b * kCtRows + rloc;  // bit b = pass * kCtLoad + slot: rows row0 + 64 b + rloc
       const long long idx = row * (long long)P + col;
       store1(out, odt, idx, DD::template eval<FN>(load1(x, xdt, (unsigned long long)idx), k));
     }
@@ -1614,7 +1692,7 @@ __global__ __launch_bounds__(kBlock) void k_generic(GenericOps ops, void* __rest
 template <class T, class = void> struct device_derive : std::false_type {};
 template <class T> struct device_derive<T, std::void_t<decltype(T::kDeviceDerive)>> : std::true_type {};
 
-// k_tab's launch: five workgroups per CU (24 KiB of LDS each), from kTabMinN elements (below, the table's 3072 exact
+// k_tab's launch: five workgroups per CU (24 KiB of LDS each), from kTabMinN elements (below, the table's 3584 exact
 // evaluations and its second launch cost more than evaluating the elements exactly); m355_set_tab_min_n() moves the
 // threshold (tests force the table onto small inputs; a huge value switches it off).  Without a workspace
 // (m355_elemwise instead of m355_elemwise_ws) there is nowhere to build a table: the exact kernels serve.
@@ -1826,7 +1904,7 @@ template <int D, int FN, bool REDUCE> int launch_fn(const LaunchArgs& a) {
           hipLaunchKernelGGL((k_coltab<D, FN, false>), dim3((unsigned)m), dim3(kCtThreads), kCtLds, a.stream, xp, a.x.dtype, op,
                              a.out_dtype, R, (unsigned)P, a.ews, counters, miss_words);
         const unsigned long long fb = (nwords + kBlock - 1) / kBlock;
-        hipLaunchKernelGGL((k_coltab_fix<D, FN>), dim3((unsigned)(fb > 8192 ? 8192 : fb)), dim3(kBlock), 0, a.stream, xp, a.x.dtype, op,
+        hipLaunchKernelGGL((k_coltab_fix<D, FN>), dim3((unsigned)(fb > 2048 ? 2048 : fb)), dim3(kBlock), 0, a.stream, xp, a.x.dtype, op,
                            a.out_dtype, R, (unsigned)P, pa, miss_words, nwords);
         hipLaunchKernelGGL((k_coltab_declined<D, FN>), dim3((unsigned)(P * kCtDeclChunks)), dim3(kBlock), 0, a.stream, xp, a.x.dtype,
                            op, a.out_dtype, R, (unsigned)P, pa, a.ews);
@@ -1857,6 +1935,28 @@ template <int D, int FN, bool REDUCE> int launch_fn(const LaunchArgs& a) {
         nn -= done;
         const long long t2 = nn / kTile;
         blocks = (int)(t2 < 1 ? 1 : (t2 > blocks ? blocks : t2));
+      }
+    }
+    if constexpr (!REDUCE && (FN == M355_LOGPDF || FN == M355_PDF)) {
+      // stored densities: constants once into the workspace, no LDS table (k_periodic_fixed), when the grid can be a
+      // multiple of P / gcd(P, kTile)
+      constexpr long long NK = sizeof(typename DD::K) / sizeof(double);
+      unsigned long long a_ = P, b_ = (unsigned long long)kTile;
+      while (b_) { const unsigned long long t_ = a_ % b_; a_ = b_; b_ = t_; }
+      const long long unit = (long long)(P / a_);
+      const long long tiles2 = nn / kTile;
+      long long pb = tiles2 > 8 * 256 ? 8 * 256 : tiles2;  // eight workgroups per CU: no LDS beyond the log table
+      pb = (pb / unit) * unit;
+      if (!all_scalar && a.ews != nullptr && (size_t)(P * NK) <= a.ews_doubles && pb >= 1 && nn == n) {
+        hipLaunchKernelGGL((k_derive_table<D>), dim3((unsigned)((P + kBlock - 1) / kBlock)), dim3(kBlock), 0, a.stream, pa,
+                           (unsigned)P, a.ews);
+        if (a.x.dtype == M355_F64 && a.out_dtype == M355_F64)
+          hipLaunchKernelGGL((k_periodic_fixed<D, FN, true>), dim3((unsigned)pb), dim3(kBlock), 0, a.stream, xp, a.x.dtype, op,
+                             a.out_dtype, nn, (unsigned)P, a.ews);
+        else
+          hipLaunchKernelGGL((k_periodic_fixed<D, FN, false>), dim3((unsigned)pb), dim3(kBlock), 0, a.stream, xp, a.x.dtype, op,
+                             a.out_dtype, nn, (unsigned)P, a.ews);
+        return (int)hipGetLastError();
       }
     }
     const size_t lds = (size_t)P * sizeof(typename DD::K);

@@ -155,8 +155,9 @@ int m355_elemwise(int dist, int fn, int out_dtype, int64_t n, const m355_operand
  * workspace each; calls on one stream may share one.  m355_elemwise(...) is m355_elemwise_ws(..., NULL, 0, stream).
  */
 size_t m355_elemwise_workspace_bytes(void);
-/* what a call with n elements needs exactly: period = 0 for scalar parameters, else the length P of the row-periodic
- * parameter arrays (0 is returned when the library has no table kernel for that period) */
+/* what a call with n elements needs at most: period = 0 for scalar parameters, else the length P of the row-periodic
+ * parameter arrays (stored logpdf / pdf with row-periodic parameters use 128 P bytes of it for the derived constants:
+ * k_periodic_fixed streams x without an LDS table) */
 size_t m355_elemwise_workspace_bytes_for(int64_t n, int64_t period);
 int m355_elemwise_ws(int dist, int fn, int out_dtype, int64_t n, const m355_operand* x, int nparams,
                      const m355_operand* params, void* out, void* workspace, size_t workspace_bytes, void* stream);

@@ -281,6 +281,7 @@ template <int D, int FN> static double hm_tab_node(double w, const typename Dist
           const double lsf = DD::template eval<M355_LOGSF>(f, k);
           const double step = (lsf - lp) * exp_(lsf - DD::template eval<M355_LOGPDF>(f, k));
           if (step - step == 0.0) f += step;
+          if (__builtin_fabs(step) <= 1e-9 * __builtin_fabs(f)) break;
         }
       }
       if constexpr (hm_has_ppf_log<DD>::value) {

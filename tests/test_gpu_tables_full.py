@@ -273,9 +273,13 @@ def test_tabulated_cdf_sf_relative_accuracy(gpu, name, params):
             rel_tab = np.abs(tab - exp) / np.abs(exp)
         held = rel_exact <= 1e-13
         if fn == "cdf" or name in ("beta", "studentt", "inversegamma", "scaledinversechisquared"):
-            # (sf = 1 - cdf in the reference of gamma / chisquared / betascaled: absolute accuracy only, in both kernels)
             assert held.mean() > 0.5, (name, fn, float(held.mean()))  # (the exact kernel itself: 1e-13 relative mostly)
-        assert np.all(rel_tab[held] <= 1e-12), (name, fn, float(rel_tab[held].max()), x[held][np.argmax(rel_tab[held])])
+            assert np.all(rel_tab[held] <= 1e-12), (name, fn, float(rel_tab[held].max()), x[held][np.argmax(rel_tab[held])])
+        else:
+            # sf = 1 - cdf in the reference of gamma / chisquared / betascaled (gamma.py:53-54, chisquared.py:77-78,
+            # betascaled.py:88-89): a small sf is a rounded difference -- absolute accuracy only, in the oracle, the exact
+            # kernel and the table alike
+            assert np.all(np.abs(tab - exp) <= 1e-14), (name, fn, float(np.abs(tab - exp).max()))
         if fn == "cdf":  # the table was used (sf = 1 - exp(logcdf) next to 1 rounds to the same double either way)
             assert np.mean(tab != exact) > 0.5
 
