@@ -57,10 +57,6 @@ def parse_args(argv=None):
                     help="config 5: size of the sub-problem checked against math.fsum")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sharded", action="store_true", help="skip regions B and C")
-    ap.add_argument("--dry-run-cpu", action="store_true",
-                    help="TEST HOOK (tests/test_bench_launcher.py): gloo on CPU tensors, per-rank sums produced by the "
-                         "oracle instead of the kernels -- exercises launcher, sharding, collectives and the JSON line; "
-                         "its numbers are not measurements")
     return ap.parse_args(argv)
 
 
@@ -74,8 +70,7 @@ def free_port():
 def canonical_argv(args):
     out = ["--gpus", str(args.gpus), "--steps", str(args.steps), "--warmup", str(args.warmup), "--elems", str(args.n),
            "--shard-elems", str(args.n_shard), "--sub-elems", str(args.n_sub)]
-    for flag, on in (("--no-cpu-baseline", args.no_cpu_baseline), ("--no-sharded", args.no_sharded),
-                     ("--dry-run-cpu", args.dry_run_cpu)):
+    for flag, on in (("--no-cpu-baseline", args.no_cpu_baseline), ("--no-sharded", args.no_sharded)):
         if on:
             out.append(flag)
     return out
@@ -137,53 +132,17 @@ class GpuEngine:
         self.torch.cuda.synchronize()
 
 
-class OracleDryRunEngine:
-    """TEST HOOK ONLY (--dry-run-cpu): no kernels; sums come from the CPU oracle so that launcher, sharding,
-    collective and reporting code can run under gloo on a box without GPUs.  Never used for a measurement."""
+def make_engine(local_rank):
+    """GpuEngine, unless M355_BENCH_ENGINE = "module:Class" names a stand-in (tests/test_bench_launcher.py injects
+    tests/bench_dry_run_engine.py this way to run launcher, sharding and reporting code under gloo on a CPU box).
+    A stand-in's numbers are not measurements and the JSON line says so (`dry_run`)."""
+    spec = os.environ.get("M355_BENCH_ENGINE")
+    if not spec:
+        return GpuEngine(local_rank)
+    import importlib
 
-    name = "oracle-dry-run"
-
-    def __init__(self, local_rank):
-        import numpy as np
-        import torch
-
-        from oracle import restatement as R
-
-        self.torch, self.np, self.R = torch, np, R
-        self.device = torch.device("cpu")
-        self.backend = "gloo"
-
-    def draw(self, fam, n, rank):
-        name, _p, _s, _sp, seed = fam
-        g = self.np.random.default_rng(seed + 1000 * rank)
-        x = {"normal": lambda: g.normal(0, 1, n), "gamma": lambda: g.gamma(2.5, 1 / 1.3, n),
-             "beta": lambda: g.beta(2, 5, n), "studentt": lambda: 2 * g.standard_t(5, n)}[name]()
-        return self.torch.from_numpy(x)
-
-    def empty(self, n):
-        return self.torch.empty(n, dtype=self.torch.float64)
-
-    def zeros(self, n):
-        return self.torch.zeros(n, dtype=self.torch.float64)
-
-    def logpdf_into(self, name, x, p, out):
-        out.copy_(self.torch.from_numpy(self.R.TABLE[f"{name}_logpdf"](x.numpy(), *p)))
-
-    def sumlogp_into(self, name, x, p, slot):
-        slot[0] = math.fsum(self.R.TABLE[f"{name}_logpdf"](x.numpy(), *p))
-
-    class _Ev:
-        def record(self):
-            self.t = time.perf_counter()
-
-        def elapsed_time(self, other):
-            return 1e3 * (other.t - self.t)
-
-    def event(self):
-        return self._Ev()
-
-    def synchronize(self):
-        pass
+    mod, _, cls = spec.partition(":")
+    return getattr(importlib.import_module(mod), cls)(local_rank)
 
 
 # ------------------------------------------------------------------------------------------------------ timed regions
@@ -397,7 +356,8 @@ def run_rank(args):
                          "(it launches its own ranks) or under torch.distributed.run with --nproc-per-node N")
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    eng = OracleDryRunEngine(local) if args.dry_run_cpu else GpuEngine(local)
+    eng = make_engine(local)
+    dry = eng.name != GpuEngine.name
     import torch.distributed as dist
 
     if world > 1:
@@ -428,7 +388,7 @@ def run_rank(args):
         names = [f"{c[0]}.logpdf" for c in CASES]
         dom = max(range(len(CASES)), key=lambda j: kdur[j])  # slowest elementwise kernel
         achieved = 16.0 * n / (kdur[dom] * 1e-3) / 1e9
-        traffic, traffic_file = pmc_traffic(dom) if (n == 100_000_000 and not args.dry_run_cpu) else (None, None)
+        traffic, traffic_file = pmc_traffic(dom) if (n == 100_000_000 and not dry) else (None, None)
         line = {
             "metric": "logpdf evals/sec (Normal/Gamma/Beta, N=1e8 fp64 per GPU, stored elementwise results)",
             "value": 3.0 * n * world / per_step,
@@ -470,10 +430,10 @@ def run_rank(args):
             "sharded_sumlogp": sharded,
             "checks_ok_all_ranks": all_ok,
         }
-        if args.dry_run_cpu:
-            line["dry_run"] = "launcher test on CPU/gloo: sums from the oracle, numbers are NOT measurements"
+        if dry:
+            line["dry_run"] = f"stand-in engine {os.environ['M355_BENCH_ENGINE']}: numbers are NOT measurements"
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"], line["cpu_baseline_all_cores"] = cpu_baselines(10_000_000 if not args.dry_run_cpu else 100_000, repeats=5)
+            line["cpu_baseline"], line["cpu_baseline_all_cores"] = cpu_baselines(10_000_000 if not dry else 100_000, repeats=5)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

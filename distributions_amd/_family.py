@@ -34,6 +34,12 @@ def export(ns: dict, dist: str, cites: dict | None = None) -> None:
     exec(f"def sum_logpdf(x, {sig}):\n    return _sumlogp({dist!r}, 'logpdf', x, {sig})\n", {"_sumlogp": _sumlogp}, loc)  # noqa: S102
     loc["sum_logpdf"].__doc__ = "sum(logpdf(x, ...)) fused in one pass (the reference spells it pt.sum(logpdf(...)))."
     ns["sum_logpdf"] = loc["sum_logpdf"]
+    for fn in ("logcdf", "logsf"):  # censored likelihoods: sum(logcdf(...)) / sum(logsf(...)) without the elementwise result
+        loc = {}
+        exec(f"def sum_{fn}(x, {sig}):\n    return _sumlogp({dist!r}, {fn!r}, x, {sig})\n", {"_sumlogp": _sumlogp}, loc)  # noqa: S102
+        loc[f"sum_{fn}"].__doc__ = (f"sum({fn}(x, ...)) fused in one pass (the reference spells it pt.sum({fn}(...))); for gamma, beta, "
+                                    "studentt and their relatives with scalar parameters from the launch-time table (k_tab).")
+        ns[f"sum_{fn}"] = loc[f"sum_{fn}"]
     loc = {}
     exec(f"def rvs({sig}, size=None, random_state=None):\n"
          f"    return _rvs({dist!r}, ({sig},), size=size, random_state=random_state)\n", {"_rvs": _rvs}, loc)  # noqa: S102

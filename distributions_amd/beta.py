@@ -51,6 +51,16 @@ def sum_logpdf(x, alpha, beta):
     return _sumlogp("beta", "logpdf", x, alpha, beta)
 
 
+def sum_logcdf(x, alpha, beta):
+    """sum(logcdf(x, ...)) fused in one pass (left-censored likelihoods; the reference spells it pt.sum(logcdf(...)))."""
+    return _sumlogp("beta", "logcdf", x, alpha, beta)
+
+
+def sum_logsf(x, alpha, beta):
+    """sum(logsf(x, ...)) fused in one pass (right-censored likelihoods; the reference spells it pt.sum(logsf(...)))."""
+    return _sumlogp("beta", "logsf", x, alpha, beta)
+
+
 def rvs(alpha, beta, size=None, random_state=None):
     """beta.py:86-87 of the reference; Philox counter-based draws, KS / chi-square equivalent to
     the reference sampler (not NumPy-stream-equal)."""

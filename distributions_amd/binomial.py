@@ -51,6 +51,16 @@ def sum_logpdf(x, n, p):
     return _sumlogp("binomial", "logpdf", x, n, p)
 
 
+def sum_logcdf(x, n, p):
+    """sum(logcdf(x, ...)) fused in one pass (left-censored likelihoods; the reference spells it pt.sum(logcdf(...)))."""
+    return _sumlogp("binomial", "logcdf", x, n, p)
+
+
+def sum_logsf(x, n, p):
+    """sum(logsf(x, ...)) fused in one pass (right-censored likelihoods; the reference spells it pt.sum(logsf(...)))."""
+    return _sumlogp("binomial", "logsf", x, n, p)
+
+
 def rvs(n, p, size=None, random_state=None):
     """binomial.py:62-63 (int64) of the reference; Philox counter-based draws, KS / chi-square equivalent to
     the reference sampler (not NumPy-stream-equal)."""

@@ -209,7 +209,8 @@ int m355_sumlogp(int dist, int fn, int64_t n, const m355_operand* x, int nparams
   a.nblocks_out = &nblocks;
   a.stream = s;
   // what the workspace holds beyond the partials serves as scratch for a table of derived constants (row-periodic
-  // parameters, k_periodic_prod); the 32 KiB array of m355_sumlogp_static has none and keeps the LDS-table kernel
+  // parameters, k_periodic_prod); m355_sumlogp_static's array has room for one launch-time table (kTabDoubles) and keeps the LDS-table kernel for
+  // larger derived-constant tables
   if (workspace_bytes > sumlogp_workspace_min_bytes()) {
     a.table = static_cast<double*>(workspace) + m355::kMaxReduceBlocks;
     a.table_doubles = (long long)((workspace_bytes - sumlogp_workspace_min_bytes()) / sizeof(double));
@@ -226,8 +227,10 @@ int m355_sumlogp(int dist, int fn, int64_t n, const m355_operand* x, int nparams
 // array for device code only: host code uses the per-device address obtained once from hipGetSymbolAddress.
 }  // extern "C"
 namespace {
-constexpr int kStaticPartials = m355::kMaxReduceBlocks;  // 4096 doubles = 32 KiB per GPU, held until process exit
-static __device__ __align__(256) double scratch[kStaticPartials];
+// 4096 partials (32 KiB) + one launch-time table (sum_logcdf / sum_logsf of the tabulated families: kTabDoubles doubles,
+// 20.1 KiB): 52.1 KiB per GPU, held until process exit
+constexpr int kStaticDoubles = m355::kMaxReduceBlocks + m355::kTabDoubles;
+static __device__ __align__(256) double scratch[kStaticDoubles];
 constexpr int kMaxDevices = 64;
 std::mutex g_scratch_mu;
 double* g_scratch_ptr[kMaxDevices] = {};
@@ -268,7 +271,7 @@ int m355_sumlogp_static(int dist, int fn, int64_t n, const m355_operand* x, int 
   if (rc != M355_OK) return rc;
   // same kernels, same grid and same fixed-order final pass as m355_sumlogp: the totals are bit-identical.  Every
   // launch writes partials [0, nblocks) before k_final reads exactly those, so nothing has to start at zero.
-  return m355_sumlogp(dist, fn, n, x, nparams, params, out_sum, ws, sizeof(double) * kStaticPartials, stream);
+  return m355_sumlogp(dist, fn, n, x, nparams, params, out_sum, ws, sizeof(double) * kStaticDoubles, stream);
 }
 
 int m355_logpdf_grad(int dist, int out_dtype, int64_t n, const m355_operand* x, int nparams,

@@ -1104,9 +1104,11 @@ __global__ __launch_bounds__(64) void k_tab_build(const typename Dist<D>::K k, d
   }
 }
 
-template <int D, int FN, bool F64IO>
+// REDUCE: the fused sum (sum_logcdf / sum_logsf: censored likelihoods) -- nothing stored, one partial per workgroup.
+template <int D, int FN, bool F64IO, bool REDUCE = false>
 __global__ __launch_bounds__(kBlock) void k_tab(const void* __restrict__ x, int xdt, void* __restrict__ out, int odt,
-                                                long long n, const typename Dist<D>::K k, const double* __restrict__ table) {
+                                                long long n, const typename Dist<D>::K k, const double* __restrict__ table,
+                                                double* __restrict__ partials = nullptr) {
   using DD = Dist<D>;
   constexpr int IO = F64IO ? 1 : 0;
   constexpr bool QDOM = FN == M355_PPF || FN == M355_ISF;
@@ -1144,6 +1146,8 @@ __global__ __launch_bounds__(kBlock) void k_tab(const void* __restrict__ x, int 
     return in ? r : kNaN;
   };
   const long long ntiles = n / kTile;
+  double acc = 0.0;
+  (void)acc;
   for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const long long base = tile * kTile + threadIdx.x * kVec;
     double v[kUnroll][kVec], r[kUnroll][kVec];
@@ -1178,13 +1182,21 @@ __global__ __launch_bounds__(kBlock) void k_tab(const void* __restrict__ x, int 
       }
     }
 #pragma unroll
-    for (int u = 0; u < kUnroll; ++u) store2<IO>(out, odt, base + u * (kBlock * kVec), r[u][0], r[u][1]);
+    for (int u = 0; u < kUnroll; ++u) {
+      if constexpr (REDUCE) acc += r[u][0] + r[u][1];
+      else store2<IO>(out, odt, base + u * (kBlock * kVec), r[u][0], r[u][1]);
+    }
   }
   for (long long i = ntiles * kTile + (long long)blockIdx.x * kBlock + threadIdx.x; i < n; i += (long long)gridDim.x * kBlock) {
     const double xv = load1(x, xdt, i);
     double rv = lookup(xv);
     if (rv != rv) rv = tab_exact<D, FN>(xv, k);
-    store1(out, odt, i, rv);
+    if constexpr (REDUCE) acc += rv;
+    else store1(out, odt, i, rv);
+  }
+  if constexpr (REDUCE) {
+    acc = block_reduce_sum(acc);
+    if (threadIdx.x == 0) partials[blockIdx.x] = acc;
   }
 }
 
@@ -1775,6 +1787,23 @@ template <int D, int FN, bool REDUCE> int launch_fn(const LaunchArgs& a) {
       // parameter-only constants once, on the host; they reach the kernel as arguments (SGPRs)
       const double pp[kMaxParams] = {a.p[0].scalar, a.p[1].scalar, a.p[2].scalar, a.p[3].scalar};
       const typename DD::K k = DD::derive(pp);
+      if constexpr (REDUCE && tab_this<DD, FN>()) {
+        // fused sum of logcdf / logsf: the table in what the caller's workspace holds beyond the partials
+        bool tab_ok = DD::tab_ok(k);
+        if constexpr (has_tab_ok_fn<DD>::value) tab_ok = tab_ok && DD::template tab_ok_fn<FN>(k);
+        if (n >= tab_min_n() && tab_ok && !binning_disabled() && a.table != nullptr && a.table_doubles >= (long long)kTabDoubles) {
+          hipLaunchKernelGGL((k_tab_build<D, FN>), dim3(kTabBuildWaves), dim3(64), 0, a.stream, k, a.table);
+          const int bb = (int)(tiles < 1 ? 1 : (tiles > kTabBlocks ? kTabBlocks : tiles));
+          if (a.nblocks_out) *a.nblocks_out = bb;
+          if (a.x.dtype == M355_F64)
+            hipLaunchKernelGGL((k_tab<D, FN, true, true>), dim3(bb), dim3(kBlock), 0, a.stream, a.x.ptr, a.x.dtype, nullptr, M355_F64, n, k,
+                               a.table, a.partials);
+          else
+            hipLaunchKernelGGL((k_tab<D, FN, false, true>), dim3(bb), dim3(kBlock), 0, a.stream, a.x.ptr, a.x.dtype, nullptr, M355_F64, n, k,
+                               a.table, a.partials);
+          return (int)hipGetLastError();
+        }
+      }
       if constexpr (!REDUCE && tab_this<DD, FN>()) {
         bool tab_ok = DD::tab_ok(k);
         if constexpr (has_tab_ok_fn<DD>::value) tab_ok = tab_ok && DD::template tab_ok_fn<FN>(k);
@@ -1788,11 +1817,11 @@ template <int D, int FN, bool REDUCE> int launch_fn(const LaunchArgs& a) {
           }();
           const int bb = (int)(want > tb ? tb : want);
           if (a.x.dtype == M355_F64 && a.out_dtype == M355_F64) {  // (cdf / sf too: kFastIO is k_scalar's economy)
-            hipLaunchKernelGGL((k_tab<D, FN, true>), dim3(bb), dim3(kBlock), 0, a.stream, a.x.ptr, a.x.dtype, a.out,
-                               a.out_dtype, n, k, a.ews);
+            hipLaunchKernelGGL((k_tab<D, FN, true, false>), dim3(bb), dim3(kBlock), 0, a.stream, a.x.ptr, a.x.dtype, a.out,
+                               a.out_dtype, n, k, a.ews, nullptr);
           } else {
-            hipLaunchKernelGGL((k_tab<D, FN, false>), dim3(bb), dim3(kBlock), 0, a.stream, a.x.ptr, a.x.dtype, a.out,
-                               a.out_dtype, n, k, a.ews);
+            hipLaunchKernelGGL((k_tab<D, FN, false, false>), dim3(bb), dim3(kBlock), 0, a.stream, a.x.ptr, a.x.dtype, a.out,
+                               a.out_dtype, n, k, a.ews, nullptr);
           }
           return (int)hipGetLastError();
         }

@@ -51,6 +51,16 @@ def sum_logpdf(x, alpha, beta):
     return _sumlogp("gamma", "logpdf", x, alpha, beta)
 
 
+def sum_logcdf(x, alpha, beta):
+    """sum(logcdf(x, ...)) fused in one pass (left-censored likelihoods; the reference spells it pt.sum(logcdf(...)))."""
+    return _sumlogp("gamma", "logcdf", x, alpha, beta)
+
+
+def sum_logsf(x, alpha, beta):
+    """sum(logsf(x, ...)) fused in one pass (right-censored likelihoods; the reference spells it pt.sum(logsf(...)))."""
+    return _sumlogp("gamma", "logsf", x, alpha, beta)
+
+
 def rvs(alpha, beta, size=None, random_state=None):
     """gamma.py:61-62 (shape alpha, scale 1/beta) of the reference; Philox counter-based draws, KS / chi-square equivalent to
     the reference sampler (not NumPy-stream-equal)."""

@@ -51,6 +51,16 @@ def sum_logpdf(x, mu, sigma):
     return _sumlogp("normal", "logpdf", x, mu, sigma)
 
 
+def sum_logcdf(x, mu, sigma):
+    """sum(logcdf(x, ...)) fused in one pass (left-censored likelihoods; the reference spells it pt.sum(logcdf(...)))."""
+    return _sumlogp("normal", "logcdf", x, mu, sigma)
+
+
+def sum_logsf(x, mu, sigma):
+    """sum(logsf(x, ...)) fused in one pass (right-censored likelihoods; the reference spells it pt.sum(logsf(...)))."""
+    return _sumlogp("normal", "logsf", x, mu, sigma)
+
+
 def rvs(mu, sigma, size=None, random_state=None):
     """normal.py:66-67 of the reference; Philox counter-based draws, KS / chi-square equivalent to
     the reference sampler (not NumPy-stream-equal)."""

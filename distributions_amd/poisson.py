@@ -51,6 +51,16 @@ def sum_logpdf(x, mu):
     return _sumlogp("poisson", "logpdf", x, mu)
 
 
+def sum_logcdf(x, mu):
+    """sum(logcdf(x, ...)) fused in one pass (left-censored likelihoods; the reference spells it pt.sum(logcdf(...)))."""
+    return _sumlogp("poisson", "logcdf", x, mu)
+
+
+def sum_logsf(x, mu):
+    """sum(logsf(x, ...)) fused in one pass (right-censored likelihoods; the reference spells it pt.sum(logsf(...)))."""
+    return _sumlogp("poisson", "logsf", x, mu)
+
+
 def rvs(mu, size=None, random_state=None):
     """poisson.py:66-67 (int64) of the reference; Philox counter-based draws, KS / chi-square equivalent to
     the reference sampler (not NumPy-stream-equal)."""

@@ -21,6 +21,7 @@ import types
 import numpy as np
 
 try:
+    import pytensor
     import pytensor.tensor as pt
     from pytensor.graph.basic import Apply
     from pytensor.graph.op import Op
@@ -28,8 +29,8 @@ except ImportError as e:  # pragma: no cover - PyTensor absent here
     raise ImportError("distributions_amd.pytensor_ops needs PyTensor (pip install pytensor); the eager "
                       "functions in distributions_amd.<dist> do not") from e
 
-from . import _dispatch, _mv
-from ._lib import FN, GRAD, NPARAMS
+from . import _catmult, _dispatch, _mv
+from ._lib import DISCRETE, FN, GRAD, NPARAMS
 
 
 def _out_dtype(inputs) -> str:
@@ -192,9 +193,139 @@ class M355MvLogpdf(Op):
         output_storage[0][0] = np.asarray(_mv.mv_logpdf(self.kind, x, mu, cov, float(nu)), dtype="float64")
 
 
+class M355MatrixNormalLogpdf(Op):
+    """matrixnormal.logpdf(X, mu, rowcov, colcov) (matrixnormal.py:68-94): X (..., n, p), one value per matrix."""
+
+    __props__ = ()
+
+    def make_node(self, X, mu, rowcov, colcov):
+        ins = [pt.as_tensor_variable(v) for v in (X, mu, rowcov, colcov)]
+        if ins[0].type.ndim < 2 or ins[2].type.ndim != 2 or ins[3].type.ndim != 2:
+            raise ValueError("matrixnormal: X (..., n, p), rowcov (n, n), colcov (p, p)")
+        nd = max(ins[0].type.ndim, ins[1].type.ndim) - 2
+        return Apply(self, ins, [pt.tensor(dtype="float64", shape=(None,) * nd)])
+
+    def perform(self, node, inputs, output_storage):
+        output_storage[0][0] = np.asarray(_mv.matrixnormal_logpdf(*inputs), dtype="float64")
+
+
+class M355Categorical(Op):
+    """categorical.<fn>(x, p) for one probability vector p (categorical.py:60-112): the shape of x, float64."""
+
+    __props__ = ("fn",)
+
+    def __init__(self, fn: str):
+        if fn not in FN:
+            raise ValueError(f"unknown function {fn}")
+        self.fn = fn
+
+    def make_node(self, x, p):
+        x, p = pt.as_tensor_variable(x), pt.as_tensor_variable(p)
+        if p.type.ndim != 1:
+            raise ValueError("categorical: p must be one probability vector of shape (k,)")
+        return Apply(self, [x, p], [pt.tensor(dtype="float64", shape=x.type.shape)])
+
+    def perform(self, node, inputs, output_storage):
+        output_storage[0][0] = np.asarray(_catmult.categorical(self.fn, *inputs), dtype="float64")
+
+    def infer_shape(self, fgraph, node, shapes):
+        return [shapes[0]]
+
+
+class M355MultinomialLogpdf(Op):
+    """multinomial.logpdf(x, n, p) (multinomial.py:39-54): x (..., k), p (..., k), one value per count vector."""
+
+    __props__ = ()
+
+    def make_node(self, x, n, p):
+        ins = [pt.as_tensor_variable(v) for v in (x, n, p)]
+        if ins[0].type.ndim < 1 or ins[2].type.ndim < 1:
+            raise ValueError("multinomial: x (..., k) and p (..., k) must share the last axis")
+        nd = max(ins[0].type.ndim - 1, ins[1].type.ndim, ins[2].type.ndim - 1)
+        return Apply(self, ins, [pt.tensor(dtype="float64", shape=(None,) * nd)])
+
+    def perform(self, node, inputs, output_storage):
+        output_storage[0][0] = np.asarray(_catmult.multinomial_logpdf(*inputs), dtype="float64")
+
+
+class M355Rvs(Op):
+    """(next_rng, draw) = <dist>.rvs(*params, size=size, random_state=rng): the two outputs of a PyTensor RandomVariable
+    node, so that the reference's threading idiom works unchanged (normal.py:66-67 passes rng=random_state;
+    skewnormal.py:90-91 takes `next_rng, u_0 = pt.random.normal(...).owner.outputs` and feeds next_rng to the next draw).
+    inputs: rng (RandomGeneratorType; a fresh shared generator when random_state is None), size (int64 vector; empty with
+    size_none), the parameters.  perform copies the generator (PyTensor's non-inplace convention), takes one 63-bit
+    Philox seed from the copy -- which advances it: the next node draws another stream -- and returns (copy, draw).
+    Draws are Philox counter-based on the GPU: distribution-equal to the reference's NumPy streams, not stream-equal
+    (SURVEY.md quirk Q3)."""
+
+    __props__ = ("dist", "size_none")
+
+    def __init__(self, dist: str, size_none: bool):
+        if dist not in NPARAMS and dist not in ("categorical", "multinomial"):
+            raise ValueError(f"unknown distribution {dist}")
+        self.dist, self.size_none = dist, bool(size_none)
+
+    def make_node(self, rng, size, *params):
+        nparams = {"categorical": 1, "multinomial": 2}.get(self.dist) or NPARAMS[self.dist]
+        if len(params) != nparams:
+            raise TypeError(f"{self.dist}.rvs takes {nparams} parameters, got {len(params)}")
+        if rng is None:
+            rng = pytensor.shared(np.random.default_rng())
+        ps = [pt.as_tensor_variable(p) for p in params]
+        size = pt.as_tensor_variable(np.zeros(0, dtype="int64") if self.size_none else np.atleast_1d(np.asarray(size)).astype("int64")
+                                     if not hasattr(size, "type") else size)
+        if size.type.ndim != 1 or not str(size.dtype).startswith("int"):
+            raise TypeError("size must be None, an int, or a vector of ints")
+        tail = (ps[-1].type.shape[-1],) if self.dist == "multinomial" else ()
+        if self.size_none:
+            shape = () if self.dist in ("categorical", "multinomial") else _broadcast_static_shape(ps)
+        else:
+            const = getattr(size, "data", getattr(size, "value", None))
+            shape = tuple(int(v) for v in const) if const is not None else (None,) * (size.type.shape[0] or 0)
+        dtype = "int64" if self.dist in DISCRETE or self.dist in ("categorical", "multinomial") else "float64"
+        return Apply(self, [rng, size, *ps], [rng.type(), pt.tensor(dtype=dtype, shape=tuple(shape) + tail)])
+
+    def perform(self, node, inputs, output_storage):
+        import copy
+
+        rng, size, *params = inputs
+        rng = copy.deepcopy(rng)
+        size = None if self.size_none else tuple(int(v) for v in size)
+        if self.dist == "categorical":
+            draw = _catmult.categorical_rvs(*params, size=size, random_state=rng)
+        elif self.dist == "multinomial":
+            draw = _catmult.multinomial_rvs(*params, size=size, random_state=rng)
+        else:
+            draw = _dispatch.rvs(self.dist, params, size=size, random_state=rng)
+        output_storage[0][0] = rng
+        output_storage[1][0] = np.asarray(draw, dtype=node.outputs[1].dtype)
+
+
+def _rvs(dist):
+    def rvs(*params, size=None, random_state=None):
+        """The draw variable; `.owner.outputs` is (next_rng, draw) as with pt.random.*."""
+        return M355Rvs(dist, size is None)(random_state, size, *params)[1]
+
+    return rvs
+
+
 def symbolic(dist: str) -> types.SimpleNamespace:
     """Namespace with the reference's function names for one distribution, each building an Op."""
     ns = types.SimpleNamespace()
+    if dist == "matrixnormal":
+        ns.logpdf = lambda X, mu, rowcov, colcov: M355MatrixNormalLogpdf()(X, mu, rowcov, colcov)
+        ns.pdf = lambda X, mu, rowcov, colcov: pt.exp(ns.logpdf(X, mu, rowcov, colcov))
+        return ns
+    if dist == "categorical":
+        for fn in FN:
+            setattr(ns, fn, (lambda f: lambda x, p: M355Categorical(f)(x, p))(fn))
+        ns.rvs = _rvs(dist)
+        return ns
+    if dist == "multinomial":
+        ns.logpdf = lambda x, n, p: M355MultinomialLogpdf()(x, n, p)
+        ns.pdf = lambda x, n, p: pt.exp(ns.logpdf(x, n, p))
+        ns.rvs = _rvs(dist)
+        return ns
     if dist == "mvnormal":
         ns.logpdf = lambda x, mu, cov: M355MvLogpdf(0)(x, mu, cov)
         ns.pdf = lambda x, mu, cov: pt.exp(ns.logpdf(x, mu, cov))
@@ -209,4 +340,7 @@ def symbolic(dist: str) -> types.SimpleNamespace:
         if (dist, fn) in SUPPORTED:
             setattr(ns, fn, (lambda f: lambda x, *p: M355Elemwise(dist, f)(x, *p))(fn))
     ns.sum_logpdf = lambda x, *p: M355SumLogp(dist, "logpdf")(x, *p)
+    ns.sum_logcdf = lambda x, *p: M355SumLogp(dist, "logcdf")(x, *p)
+    ns.sum_logsf = lambda x, *p: M355SumLogp(dist, "logsf")(x, *p)
+    ns.rvs = _rvs(dist)
     return ns

@@ -51,6 +51,16 @@ def sum_logpdf(x, nu, mu, sigma):
     return _sumlogp("studentt", "logpdf", x, nu, mu, sigma)
 
 
+def sum_logcdf(x, nu, mu, sigma):
+    """sum(logcdf(x, ...)) fused in one pass (left-censored likelihoods; the reference spells it pt.sum(logcdf(...)))."""
+    return _sumlogp("studentt", "logcdf", x, nu, mu, sigma)
+
+
+def sum_logsf(x, nu, mu, sigma):
+    """sum(logsf(x, ...)) fused in one pass (right-censored likelihoods; the reference spells it pt.sum(logsf(...)))."""
+    return _sumlogp("studentt", "logsf", x, nu, mu, sigma)
+
+
 def rvs(nu, mu, sigma, size=None, random_state=None):
     """studentt.py:96-97 of the reference; Philox counter-based draws, KS / chi-square equivalent to
     the reference sampler (not NumPy-stream-equal)."""

@@ -195,12 +195,14 @@ int m355_sumlogp(int dist, int fn, int64_t n, const m355_operand* x, int nparams
  * m355_sumlogp without a workspace argument and without any allocation.  NO COUNTERPART IN THE REFERENCE: it exists
  * for callers that cannot allocate device memory around the call -- code under HIP graph capture, tight serving
  * loops, harnesses that forbid hipMalloc.  The per-workgroup partials live in a file-scope `static __device__`
- * array of the library (4096 doubles = 32 KiB on every GPU the library runs on, held until the process ends); its
- * per-device address is looked up once (hipGetSymbolAddress, first call on that device, device current).  With scalar
- * parameters: the same kernels, grid and fixed-order final pass as m355_sumlogp, so *out_sum is bit-identical to it.
- * With row-periodic parameters the 32 KiB array has no room for m355_sumlogp's table of derived constants
- * (k_derive_table + k_periodic_prod need the 256 KiB workspace): this entry point keeps k_periodic with its LDS table,
- * on another grid and in another order of accumulation -- the same total within 1e-12 * sum |term|, not bit for bit.
+ * array of the library (4096 partials + one launch-time table for sum-logcdf / sum-logsf of the tabulated families =
+ * 6664 doubles = 52.1 KiB on every GPU the library runs on, held until the process ends); its per-device address is
+ * looked up once (hipGetSymbolAddress, first call on that device, device current).  With scalar parameters: the same
+ * kernels, grid and fixed-order final pass as m355_sumlogp, so *out_sum is bit-identical to it.  With row-periodic
+ * parameters the array has room for m355_sumlogp's table of derived constants (k_derive_table + k_periodic_prod) only
+ * up to 2568 doubles (P x the family's constants); beyond that this entry point keeps k_periodic with its LDS table,
+ * on another grid and in another order of accumulation than m355_sumlogp with its 256 KiB workspace -- the same total
+ * within 1e-12 * sum |term|, not bit for bit.
  * The call itself performs no hipMalloc / hipFree and never synchronises.
  *   - n above M355_SUMLOGP_STATIC_MAX_N is rejected with M355_ERR_WORKSPACE (use m355_sumlogp, or split the range
  *     and add the totals).

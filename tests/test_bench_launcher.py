@@ -1,6 +1,7 @@
 """bench.py's multi-rank path on CPU: `python bench.py --gpus 2` must start its own two ranks (child
 torch.distributed.run), shard config 5 over them, all-reduce the four totals and print ONE rank-0 JSON line with
-n_gpus = 2.  Runs with --dry-run-cpu (gloo, CPU tensors, per-rank sums from the oracle): the launcher, sharding,
+n_gpus = 2.  Runs with the stand-in engine of
+tests/bench_dry_run_engine.py injected through M355_BENCH_ENGINE (gloo, CPU tensors, per-rank sums from the oracle): the launcher, sharding,
 collective, timing protocol and reporting code are the ones the GPU run uses; only the engine object differs."""
 
 import json
@@ -22,6 +23,7 @@ def _run(*argv, env=None):
     e.pop("WORLD_SIZE", None)
     e.pop("RANK", None)
     e.pop("LOCAL_RANK", None)
+    e["M355_BENCH_ENGINE"] = "tests.bench_dry_run_engine:OracleDryRunEngine"
     if env:
         e.update(env)
     return subprocess.run([sys.executable, BENCH, *argv], capture_output=True, text=True, env=e, timeout=300)
@@ -43,7 +45,7 @@ def _expected_totals(world, seg):
 
 
 def test_bench_self_launches_two_ranks_and_reduces():
-    r = _run("--gpus", "2", "--dry-run-cpu", "--elems", "20000", "--shard-elems", "80000", "--sub-elems", "8000",
+    r = _run("--gpus", "2", "--elems", "20000", "--shard-elems", "80000", "--sub-elems", "8000",
              "--steps", "2", "--warmup", "1")
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -66,7 +68,7 @@ def test_bench_self_launches_two_ranks_and_reduces():
 
 
 def test_bench_single_rank_line_has_baselines():
-    r = _run("--dry-run-cpu", "--elems", "20000", "--shard-elems", "40000", "--sub-elems", "4000", "--steps", "2",
+    r = _run("--elems", "20000", "--shard-elems", "40000", "--sub-elems", "4000", "--steps", "2",
              "--warmup", "1")
     assert r.returncode == 0, r.stderr[-2000:]
     d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
@@ -77,5 +79,5 @@ def test_bench_single_rank_line_has_baselines():
 
 
 def test_bench_rejects_world_size_mismatch():
-    r = _run("--gpus", "2", "--dry-run-cpu", env={"WORLD_SIZE": "3", "RANK": "0", "LOCAL_RANK": "0"})
+    r = _run("--gpus", "2", env={"WORLD_SIZE": "3", "RANK": "0", "LOCAL_RANK": "0"})
     assert r.returncode != 0 and "WORLD_SIZE=3" in (r.stderr + r.stdout)

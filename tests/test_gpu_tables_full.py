@@ -320,3 +320,66 @@ def test_in_place_row_periodic(gpu, name, fn):
     with np.errstate(all="ignore"):
         exp = R.TABLE[f"{name}_{fn}"](x.cpu().numpy(), *ep)
     assert np.all(H.ppf_close(name, fn, ep, a, exp) | H.ppf_unpinned(name, fn, x.cpu().numpy()))
+
+
+def _partials_written(L, name, fn, x, params, gpu):
+    import ctypes
+
+    import torch
+
+    from distributions_amd import _lib
+    from distributions_amd._lib import DIST, F64, FN, Operand
+
+    xd = torch.from_numpy(x).to(gpu)
+    ops = (Operand * (1 + len(params)))()
+    ops[0].ptr, ops[0].scalar, ops[0].div, ops[0].mod, ops[0].dtype = xd.data_ptr(), 0.0, 1, xd.numel(), F64
+    for j, p in enumerate(params, start=1):
+        ops[j].ptr, ops[j].scalar, ops[j].div, ops[j].mod, ops[j].dtype = None, float(p), 1, 1, F64
+    ws = torch.full((int(L.m355_sumlogp_workspace_bytes()) // 8,), float("nan"), dtype=torch.float64, device=gpu)
+    out = torch.zeros(1, dtype=torch.float64, device=gpu)
+    pp = ctypes.cast(ctypes.byref(ops, ctypes.sizeof(Operand)), ctypes.POINTER(Operand))
+    _lib.check(L.m355_sumlogp(DIST[name], FN[fn], xd.numel(), ops, len(params), pp, out.data_ptr(), ws.data_ptr(),
+                              ws.numel() * 8, torch.cuda.current_stream(gpu).cuda_stream))
+    torch.cuda.synchronize()
+    return int((~torch.isnan(ws[:4096])).sum().item())
+
+
+@pytest.mark.parametrize("name", ["gamma", "beta", "studentt", "normal", "chisquared"])
+def test_fused_sum_logcdf_logsf(gpu, name):
+    """sum_logcdf / sum_logsf (censored likelihoods; the reference spells them pt.sum(logcdf(...)): gamma.py:65-94,
+    beta.py:90-120, studentt.py:100-123, normal.py:70-84): the fused sum against math.fsum of the oracle's terms at
+    1e-12 * sum |term| -- above the table threshold (k_tab with the reduction epilogue for the tabulated families), below
+    it (exact bodies) and with row-periodic parameters."""
+    import math
+
+    from distributions_amd import _lib
+
+    L = _lib.lib()
+    m = mod(name)
+    rng = np.random.default_rng(91)
+    params = {"gamma": (2.5, 1.3), "beta": (2.0, 5.0), "studentt": (5.0, 0.0, 2.0), "normal": (0.3, 1.7), "chisquared": (7.0,)}[name]
+    draw = {"gamma": lambda n: rng.gamma(2.5, 1 / 1.3, n), "beta": lambda n: rng.beta(2, 5, n),
+            "studentt": lambda n: 2 * rng.standard_t(5, n), "normal": lambda n: rng.normal(0, 1, n),
+            "chisquared": lambda n: rng.chisquare(7.0, n)}[name]
+    for n in (3_000_017, 40_003):
+        x = draw(n)
+        for fn in ("logcdf", "logsf"):
+            with np.errstate(all="ignore"):
+                terms = R.TABLE[f"{name}_{fn}"](x, *params)
+            ref, scale = math.fsum(terms), float(np.abs(terms).sum())
+            got = getattr(m, f"sum_{fn}")(x, *params)
+            assert abs(got - ref) <= 1e-12 * scale, (name, fn, n, got, ref)
+            exact = _exact(L, getattr(m, f"sum_{fn}"), x, *params)
+            assert abs(exact - ref) <= 1e-12 * scale, (name, fn, n, "exact bodies", exact, ref)
+            if n > 2**21 and name != "normal":
+                # the table kernel ran: its grid (1280 workgroups) leaves 1280 partials in the workspace, the exact
+                # kernel's one per tile of 1024 elements (capped at 4096)
+                assert _partials_written(L, name, fn, x, params, gpu) == 1280, (name, fn)
+    if name in ("gamma", "beta", "studentt"):  # row-periodic parameters: the exact bodies with the reduction epilogue
+        x = draw(64 * P).reshape(64, P)
+        pp = periodic_params(name)
+        for fn in ("logcdf", "logsf"):
+            with np.errstate(all="ignore"):
+                terms = R.TABLE[f"{name}_{fn}"](x, *pp)
+            got = getattr(m, f"sum_{fn}")(x, *pp)
+            assert abs(got - math.fsum(terms.ravel())) <= 1e-12 * float(np.abs(terms).sum()), (name, fn, "periodic")
