@@ -281,7 +281,9 @@ class M355Rvs(Op):
             shape = () if self.dist in ("categorical", "multinomial") else _broadcast_static_shape(ps)
         else:
             const = getattr(size, "data", getattr(size, "value", None))
-            shape = tuple(int(v) for v in const) if const is not None else (None,) * (size.type.shape[0] or 0)
+            if const is None and size.type.shape[0] is None:
+                raise TypeError("size must have a static length")
+            shape = tuple(int(v) for v in const) if const is not None else (None,) * size.type.shape[0]
         dtype = "int64" if self.dist in DISCRETE or self.dist in ("categorical", "multinomial") else "float64"
         return Apply(self, [rng, size, *ps], [rng.type(), pt.tensor(dtype=dtype, shape=tuple(shape) + tail)])
 

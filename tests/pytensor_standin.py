@@ -15,6 +15,31 @@ class TensorType:
     def __init__(self, dtype, shape):
         self.dtype, self.shape, self.ndim = str(np.dtype(dtype)), tuple(shape), len(shape)
 
+    def __call__(self, name=None):
+        return Variable(self.dtype, self.shape, name)
+
+
+class RandomGeneratorType:
+    """The type of a variable that holds a numpy Generator (PyTensor: pytensor.tensor.random.type)."""
+
+    dtype, shape, ndim = "object", (), 0
+
+    def __call__(self, name=None):
+        v = Variable("float64", (), name)
+        v.type = self
+        return v
+
+
+def shared(value, name=None):
+    """pytensor.shared: a variable that carries its value (Generators and arrays)."""
+    if isinstance(value, np.random.Generator):
+        v = RandomGeneratorType()(name)
+        v.value = value
+        return v
+    v = as_tensor_variable(np.asarray(value))
+    v.name = name
+    return v
+
 
 class Apply:
     def __init__(self, op, inputs, outputs):
@@ -55,6 +80,8 @@ class Op:
 def as_tensor_variable(v):
     if isinstance(v, Variable):
         return v
+    if isinstance(v, (list, tuple)) and any(isinstance(e, Variable) for e in v):
+        raise TypeError("the stand-in does not stack variables")
     if isinstance(v, bool):
         a = np.asarray(v)
     elif isinstance(v, int):  # PyTensor: the smallest integer type that holds a Python int
@@ -164,7 +191,7 @@ def _evaluate(outputs, givens):
         if id(v) in cache:
             return cache[id(v)]
         if v in givens:
-            r = np.asarray(givens[v], dtype=v.dtype)
+            r = givens[v] if isinstance(v.type, RandomGeneratorType) else np.asarray(givens[v], dtype=v.dtype)
         elif v.owner is None:
             if v.value is None:
                 raise ValueError(f"no value for input {v.name}")
@@ -225,9 +252,10 @@ def installed():
     pt.dmatrix = lambda name=None: Variable("float64", (None, None), name)
     pt.fmatrix = lambda name=None: Variable("float32", (None, None), name)
     pt.lvector = lambda name=None: Variable("int64", (None,), name)
+    pt.dtensor3 = lambda name=None: Variable("float64", (None, None, None), name)
     pt.broadcast_shape = lambda *shapes, arrays_are_shapes=False: tuple(np.broadcast_shapes(*shapes))
     root = types.ModuleType("pytensor")
-    root.tensor, root.grad, root.function = pt, grad, function
+    root.tensor, root.grad, root.function, root.shared = pt, grad, function, shared
     graph = types.ModuleType("pytensor.graph")
     basic, opm = types.ModuleType("pytensor.graph.basic"), types.ModuleType("pytensor.graph.op")
     basic.Apply, opm.Op = Apply, Op

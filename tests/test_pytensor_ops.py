@@ -93,7 +93,28 @@ def test_make_node_logic_with_standin():
         assert ops.M355MvLogpdf(0)(pt.dmatrix(), pt.dvector(), pt.dmatrix()).type.ndim == 1
         assert ops.M355SumLogp("gamma")(x, 2.5, 1.3).type.shape == ()
         ns = ops.symbolic("beta")
-        assert {"logpdf", "logcdf", "logsf", "ppf", "pdf", "cdf", "sf", "isf", "sum_logpdf"} <= set(vars(ns))
+        assert {"logpdf", "logcdf", "logsf", "ppf", "pdf", "cdf", "sf", "isf", "sum_logpdf", "sum_logcdf", "sum_logsf",
+                "rvs"} <= set(vars(ns))
+        # rvs: a RandomVariable-shaped node -- outputs (next_rng, draw), static shape and dtype of the draw
+        rng = pytensor.shared(np.random.default_rng(3))
+        d = ops.symbolic("normal").rvs(0.0, pt.constant(np.ones((4, 1))), size=(5, 4, 3), random_state=rng)
+        assert d.owner.outputs[1] is d and d.type.shape == (5, 4, 3) and d.dtype == "float64"
+        assert type(d.owner.outputs[0].type) is type(rng.type) and d.owner.inputs[0] is rng
+        assert ops.symbolic("poisson").rvs(3.0, size=7).dtype == "int64"
+        assert ops.symbolic("gamma").rvs(pt.constant(np.ones((6, 1))), pt.constant(np.ones(2))).type.shape == (6, 2)
+        assert ops.symbolic("multinomial").rvs(10, pt.constant(np.ones(4) / 4), size=3).type.shape == (3, 4)
+        assert ops.symbolic("categorical").rvs(pt.constant(np.ones(4) / 4)).type.shape == ()
+        with pytest.raises(TypeError, match="takes 2 parameters"):
+            ops.symbolic("normal").rvs(0.0)
+        with pytest.raises(TypeError, match="size"):
+            ops.symbolic("normal").rvs(0.0, 1.0, size=pt.constant(np.ones((2, 2), dtype="int64")))
+        assert ops.M355MatrixNormalLogpdf()(pt.dtensor3(), pt.dmatrix(), pt.dmatrix(), pt.dmatrix()).type.ndim == 1
+        with pytest.raises(ValueError, match="rowcov"):
+            ops.M355MatrixNormalLogpdf()(pt.dvector(), pt.dmatrix(), pt.dmatrix(), pt.dmatrix())
+        assert ops.M355Categorical("logpdf")(pt.lvector(), pt.dvector()).type.shape == (None,)
+        with pytest.raises(ValueError, match="probability vector"):
+            ops.M355Categorical("logpdf")(pt.lvector(), pt.dmatrix())
+        assert ops.M355MultinomialLogpdf()(pt.dmatrix(), 10, pt.dvector()).type.ndim == 1
     assert "pytensor" not in __import__("sys").modules or HAVE
 
 
@@ -143,3 +164,60 @@ def test_ops_perform_and_l_op_with_standin(gpu):
             assert np.allclose(np.ravel(eb), gr[2].sum(axis=0), rtol=1e-11, atol=1e-11)
         with pytest.raises(NotImplementedError):
             pytensor.grad(g.logcdf(xs, a, b).sum(), [a])
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(HAVE, reason="real PyTensor present")
+def test_rvs_and_multivariate_ops_with_standin(gpu):
+    """The rvs Op threads the generator as pt.random does (normal.py:66-67; skewnormal.py:90-91 takes next_rng from
+    `.owner.outputs` for its second draw); matrixnormal / categorical / multinomial Ops against the oracle."""
+    from scipy import stats
+
+    from oracle import restatement as R
+    from tests import harness as H
+    from tests.pytensor_standin import installed
+
+    rng = np.random.default_rng(5)
+    with installed() as (ops, pytensor):
+        pt = pytensor.tensor
+        normal = ops.symbolic("normal")
+        src = pytensor.shared(np.random.default_rng(11))
+        # the reference's idiom: two draws chained through next_rng are different streams; the same generator state
+        # gives the same draw again; the input generator is not advanced (non-inplace Op)
+        next_rng, u0 = normal.rvs(0.0, 1.0, size=(200_000,), random_state=src).owner.outputs
+        v = normal.rvs(0.0, 1.0, size=(200_000,), random_state=next_rng)
+        a, b = pytensor.function([], [u0, v])()
+        assert a.shape == b.shape == (200_000,) and not np.array_equal(a, b)
+        assert abs(np.corrcoef(a, b)[0, 1]) < 0.01
+        assert stats.kstest(a, "norm").pvalue > 1e-4 and stats.kstest(b, "norm").pvalue > 1e-4
+        assert np.array_equal(u0.eval(), a)  # same generator state in, same draw out
+        assert src.value.bit_generator.state == np.random.default_rng(11).bit_generator.state
+        # parameters broadcast against size; discrete families give int64
+        g = ops.symbolic("gamma").rvs(pt.constant(np.array([[2.0], [8.0]])), 2.0, size=(2, 50_000), random_state=src).eval()
+        assert g.shape == (2, 50_000) and abs(g[0].mean() - 1.0) < 0.02 and abs(g[1].mean() - 4.0) < 0.04
+        k = ops.symbolic("poisson").rvs(4.0, size=100_000, random_state=src).eval()
+        assert k.dtype == np.int64 and abs(k.mean() - 4.0) < 0.03
+        p = np.array([0.1, 0.2, 0.3, 0.4])
+        c = ops.symbolic("categorical").rvs(pt.constant(p), size=100_000, random_state=src).eval()
+        assert c.dtype == np.int64 and np.allclose(np.bincount(c, minlength=4) / c.size, p, atol=0.01)
+        m = ops.symbolic("multinomial").rvs(20, pt.constant(p), size=(1000,), random_state=src).eval()
+        assert m.shape == (1000, 4) and np.all(m.sum(axis=1) == 20)
+        # densities
+        x = rng.integers(-1, 6, 300)
+        cat = ops.symbolic("categorical")
+        for fn in ("logpdf", "cdf", "logsf"):
+            with np.errstate(all="ignore"):
+                assert np.all(H.close(getattr(cat, fn)(pt.constant(x), pt.constant(p)).eval(), getattr(R, f"categorical_{fn}")(x, p))), fn
+        counts = rng.multinomial(20, p, size=64)
+        mn = ops.symbolic("multinomial")
+        assert np.all(H.close(mn.logpdf(pt.constant(counts), 20, pt.constant(p)).eval(), R.multinomial_logpdf(counts, 20, p)))
+        A = rng.normal(size=(3, 3))
+        B = rng.normal(size=(4, 4))
+        rowcov, colcov = A @ A.T + 3 * np.eye(3), B @ B.T + 4 * np.eye(4)
+        X, mu = rng.normal(size=(9, 3, 4)), rng.normal(size=(3, 4))
+        got = ops.symbolic("matrixnormal").logpdf(pt.constant(X), pt.constant(mu), pt.constant(rowcov), pt.constant(colcov)).eval()
+        assert np.all(H.close(got, R.matrixnormal_logpdf(X, mu, rowcov, colcov)))
+        xs = pt.dvector("x")
+        tot = ops.symbolic("gamma").sum_logcdf(xs, 2.5, 1.3).eval({xs: g[0]})
+        terms = R.gamma_logcdf(g[0], 2.5, 1.3)
+        assert abs(tot - terms.sum()) <= 1e-12 * np.abs(terms).sum()
