@@ -53,8 +53,10 @@ __host__ __device__ inline size_t frag_doubles(int d) { return (size_t)nblk16(d)
 #ifdef M355_CHOL_PROBE
 __device__ long long g_chol_ticks[64];
 #define M355_TICK(n) do { if (threadIdx.x == 0 && blockIdx.x == 0) g_chol_ticks[n] = clock64(); } while (0)
+#define M355_TICKW(n) do { if (threadIdx.x == 64 && blockIdx.x == 0 && (n) < 64) g_chol_ticks[n] = clock64(); } while (0)
 #else
 #define M355_TICK(n) do { } while (0)
+#define M355_TICKW(n) do { } while (0)
 #endif
 
 M355_DEV double readlane_d(double v, int lane) {  // `lane` must be wave-uniform
@@ -516,6 +518,24 @@ __global__ __launch_bounds__(64 * kMfmaWaves) void k_solve_mfma(const MfmaArgs a
   const long long gstride = (long long)gridDim.x * kMfmaWaves;
   d2_t raw[T][NJ];
   auto fetch = [&](long long group) {
+    if ((group * T + T) * tile_elems <= total) {
+      // whole tiles (all groups but the last): straight-line loads; lanes past a tile (d < 16 NB) read its element 0 and
+      // never use the value.  (With a branch per load the compiler put a wait for ALL outstanding loads in front of
+      // each one -- the tail path's narrower load aliased its destination -- one memory latency per load.)
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+        const long long base = (group * T + t) * tile_elems;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          const int e = 128 * j + 2 * lane;
+          const long long g = base + (e < tile_elems ? e : 0);
+          d2_t v = __builtin_nontemporal_load(reinterpret_cast<const d2_t*>(a.x + g));
+          if (MU_ROWS) v -= __builtin_nontemporal_load(reinterpret_cast<const d2_t*>(a.mu + g));
+          raw[t][j] = v;
+        }
+      }
+      return;
+    }
 #pragma unroll
     for (int t = 0; t < T; ++t) {
       const long long base = (group * T + t) * tile_elems;
@@ -695,7 +715,7 @@ __global__ __launch_bounds__(64 * kMfmaWaves) void k_solve_mfma(const MfmaArgs a
 // matrix pipe.  Every workgroup computes the same factor from the same code: results do not depend on the grid.
 constexpr int kSharedWaves = 8;
 template <int NB> __host__ __device__ constexpr size_t shared_lds_doubles() {
-  return 64 * 17 * 2 + 64 + (size_t)NB * (NB + 1) / 2 * 256 + 8 + 16 * NB + (size_t)kSharedWaves * 16 * (16 * NB + 4);
+  return 64 * 17 * 2 + 64 + (size_t)NB * (NB + 1) / 2 * 256 + 8 + 16 * NB + (size_t)kSharedWaves * (16 * (16 * NB + 4) + 128);
 }
 M355_DEV void wave_sync() {  // LDS traffic of ONE wavefront: the hardware keeps its DS operations in order; this keeps the compiler from moving them
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -901,15 +921,37 @@ __global__ __launch_bounds__(64 * kSharedWaves) void k_mvn_shared(const double* 
   double* misc = fr + NBLK * 256;       // [0] logdet
   double* mu_s = misc + 8;              // 16 NB (zero padded)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  double* st = mu_s + 16 * NB + wave * (16 * S);
+  double* st = mu_s + 16 * NB + wave * (16 * S + 128);  // 16 staged rows + a dump slot (16 bytes) per lane
   const int d = a.d;
   const int tile_elems = 16 * d;
   const long long total = a.n * (long long)d;
   const long long ntiles = (a.n + 15) / 16;
-  const long long gstride = (long long)gridDim.x * kSharedWaves;
-  d2_t raw[NJ];
-  auto fetch = [&](long long tile) {
-    const long long base = tile * tile_elems;
+  // This workgroup's tiles: blockIdx.x + k gridDim.x, k < t_cnt (neighbouring workgroups read neighbouring tiles: the
+  // grid sweeps one window of memory).  Wavefronts 1-7 take three tiles each up front (one staged in LDS, two in
+  // registers: all in flight while wavefront 0 factors), wavefront 0 one; what is left goes tile by tile to whoever
+  // asks first (an LDS counter), so the late wavefront 0 does not set the pace.
+  const long long t_lo = blockIdx.x, t_step = gridDim.x;
+  const int t_cnt = (int)((ntiles - t_lo + t_step - 1) / t_step);
+  int* next_tile = reinterpret_cast<int*>(misc + 1);
+  constexpr int kUpFront = 3 * (kSharedWaves - 1) + 1;
+  d2_t raw0[NJ], raw1[NJ];
+  auto fetch = [&](d2_t (&raw)[NJ], int k) {  // k: index within the range (k < t_cnt)
+    const long long base = (t_lo + k * t_step) * tile_elems;
+    if (base + tile_elems <= total) {
+      // a whole tile (all but the last): straight-line loads.  Lanes past the tile (d < 16 NB) read element 0 of it and
+      // never use the value: with a branch per load the compiler serialised the eight loads (a wait for all outstanding
+      // loads in front of each: the tail path's narrower load aliased its destination), one memory latency EACH.
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const int e = 128 * j + 2 * lane;
+        const bool in = e < tile_elems;
+        const long long gi = base + (in ? e : 0);
+        d2_t v = __builtin_nontemporal_load(reinterpret_cast<const d2_t*>(a.x + gi));
+        if (MU_ROWS) v -= __builtin_nontemporal_load(reinterpret_cast<const d2_t*>(a.mu + gi));
+        raw[j] = v;  // (stage() never stores the lanes past the tile: no select here, which would wait for the load)
+      }
+      return;
+    }
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
       const int e = 128 * j + 2 * lane;
@@ -927,7 +969,11 @@ __global__ __launch_bounds__(64 * kSharedWaves) void k_mvn_shared(const double* 
       raw[j] = v;
     }
   };
-  long long tile = (long long)blockIdx.x * kSharedWaves + wave;
+  auto grab = [&]() -> int {  // the next tile of the range, the same value in every lane (>= t_cnt: none left)
+    int k = 0;
+    if (lane == 0) k = atomicAdd(next_tile, 1);
+    return __builtin_amdgcn_readfirstlane(k);
+  };
   // (the mean is fetched by the LAST wavefront: wavefront 0's first memory operations are the loads of the covariance)
   if (wave == kSharedWaves - 1 && lane < 16 * NB) mu_s[lane] = (!MU_ROWS && lane < d) ? a.mu[lane] : 0.0;
   for (int e = lane; e < 16 * S; e += 64) st[e] = 0.0;  // padding columns stay zero for the whole kernel
@@ -938,43 +984,71 @@ __global__ __launch_bounds__(64 * kSharedWaves) void k_mvn_shared(const double* 
     const int e = 128 * j + 2 * lane;
     const int o0 = (int)(((float)e + 0.5f) * invd), c0 = e - o0 * d;
     const int o1 = (int)(((float)e + 1.5f) * invd), c1 = (e + 1) - o1 * d;
-    off0[j] = e < tile_elems ? o0 * S + c0 : -1;
-    off1[j] = (e + 1) < tile_elems ? o1 * S + c1 : -1;
+    off0[j] = e < tile_elems ? o0 * S + c0 : 16 * S + 2 * lane;  // (past the tile: the lane's dump slot -- no branch per store)
+    off1[j] = (e + 1) < tile_elems ? o1 * S + c1 : 16 * S + 2 * lane + 1;
   }
-  auto stage = [&]() {
+  const bool pairs = (d & 1) == 0;  // even d: the two elements of a load are neighbours in one row (16-byte aligned: S is even)
+  auto stage = [&](const d2_t (&raw)[NJ]) {
+    if (pairs) {  // one 16-byte store per load: half the LDS instructions, and no bank is hit more often than it must be
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-      if (off0[j] >= 0) st[off0[j]] = raw[j].x;
-      if (off1[j] >= 0) st[off1[j]] = raw[j].y;
+      for (int j = 0; j < NJ; ++j) *reinterpret_cast<d2_t*>(st + off0[j]) = raw[j];
+    } else {
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        st[off0[j]] = raw[j].x;
+        st[off1[j]] = raw[j].y;
+      }
     }
   };
-  // the first tile goes to the staging buffer BEFORE the factorisation (wavefront 0: behind the loads of the covariance):
-  // the load overlaps it, and no observation registers are live while wavefront 0 needs them all
+  // kA: the tile in the staging buffer, kB: the one in raw0, kC: the one in raw1 (indices within the range; >= t_cnt:
+  // none).  The staged tile goes to LDS BEFORE the factorisation (wavefront 0: behind the loads of the covariance): its
+  // load overlaps the factorisation, and wavefront 0 holds no observation registers while it needs them all.
+  int kA, kB, kC;
   __builtin_amdgcn_wave_barrier();
-  if (wave != 0 && tile < ntiles) {
-    fetch(tile);
-    stage();
-  }
-  if (wave == 0) {  // (wave-uniform branch; no workgroup barrier inside)
+  if (wave != 0) {
+    kA = wave - 1;
+    kB = kA + (kSharedWaves - 1);
+    kC = kB + (kSharedWaves - 1);
+    // (three tiles' loads issued back to back: B travels in raw1 until A has been staged out of raw0)
+    if (kA < t_cnt) fetch(raw0, kA);
+    if (kB < t_cnt) fetch(raw1, kB);
+    if (kA < t_cnt) stage(raw0);
+    if (kC < t_cnt) fetch(raw0, kC);
+  } else {
+    kA = kUpFront - 1;
+    if (lane == 0) *next_tile = kUpFront;  // (read by the others after the barrier below)
     shared_factor<NB>(cov, d, Pm, Dg, rd, fr, misc, [&]() {
-      if (tile < ntiles) {
-        fetch(tile);
-        stage();
+      if (kA < t_cnt) {
+        fetch(raw0, kA);
+        stage(raw0);
       }
     });
+    kB = grab();
+    kC = grab();
+    if (kB < t_cnt) fetch(raw0, kB);
+    if (kC < t_cnt) fetch(raw1, kC);
   }
   M355_TICK(22);
   __syncthreads();
   M355_TICK(23);
+  if (wave != 0) {  // B to raw0, C to raw1 (long arrived: register moves)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const d2_t t = raw0[j];
+      raw0[j] = raw1[j];
+      raw1[j] = t;
+    }
+  }
   double F[NBLK * 4];
 #pragma unroll
   for (int b = 0; b < NBLK * 4; ++b) F[b] = fr[b * 64 + lane];
   const double logdet = misc[0];
   const int rbase = (lane & 15) * S + (lane >> 4);
-  for (; tile < ntiles; tile += gstride) {
-    const bool more = tile + gstride < ntiles;
-    if (more) fetch(tile + gstride);  // in flight during the MFMA chain below
+  [[maybe_unused]] int tick_i = 0;
+  auto solve_tile = [&](int k) {  // the tile in the staging buffer: blocked forward substitution on the matrix pipe
+    const long long tile = t_lo + k * t_step;
     __builtin_amdgcn_wave_barrier();
+    M355_TICKW(24 + 4 * tick_i);
     double quad = 0.0;
     d4_t Y[NB];
 #pragma unroll
@@ -995,6 +1069,7 @@ __global__ __launch_bounds__(64 * kSharedWaves) void k_mvn_shared(const double* 
       for (int r = 0; r < 4; ++r) quad = __builtin_fma(y[r], y[r], quad);
     }
     __builtin_amdgcn_wave_barrier();
+    M355_TICKW(25 + 4 * tick_i);
     quad += __shfl_xor(quad, 16, 64);  // lanes l, l+16, l+32, l+48 hold the four row groups of observation l & 15
     quad += __shfl_xor(quad, 32, 64);
     const long long r = tile * 16 + lane;
@@ -1007,7 +1082,27 @@ __global__ __launch_bounds__(64 * kSharedWaves) void k_mvn_shared(const double* 
       }
       a.out[r] = v;
     }
-    if (more) stage();  // (after this tile's reads of the buffer: one wavefront, program order)
+    M355_TICKW(26 + 4 * tick_i);
+    ++tick_i;
+  };
+  // Two tiles per trip, so that the roles of raw0 / raw1 alternate without register copies (a copy would wait for the
+  // load it copies): behind every MFMA chain the loads of the next two tiles stay in flight.
+  while (kA < t_cnt) {
+    solve_tile(kA);                       // st = A, raw0 = B, raw1 = C
+    if (kB >= t_cnt) break;
+    stage(raw0);                          // (after this tile's reads of the buffer: one wavefront, program order)
+    M355_TICKW(23 + 4 * tick_i);
+    const int kD = kC < t_cnt ? grab() : t_cnt;
+    if (kD < t_cnt) fetch(raw0, kD);
+    solve_tile(kB);                       // st = B, raw1 = C, raw0 = D
+    if (kC >= t_cnt) break;
+    stage(raw1);
+    M355_TICKW(23 + 4 * tick_i);
+    const int kE = kD < t_cnt ? grab() : t_cnt;
+    if (kE < t_cnt) fetch(raw1, kE);
+    kA = kC;                              // st = C, raw0 = D, raw1 = E
+    kB = kD;
+    kC = kE;
   }
 }
 

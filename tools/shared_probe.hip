@@ -36,5 +36,8 @@ int main(int argc, char** argv) {
   printf("variant %d d=%d n=%lld kernel %.1f us | load %lld", M355_SHARED_VARIANT, d, n, best * 1e3, t[1] - t[0]);
   for (int J = 0; J < NB; ++J) printf(" | panel %d: transpose %lld sweep %lld mfma %lld", J, t[2 + 3 * J] - (J ? t[4 + 3 * (J - 1)] : t[1]), t[3 + 3 * J] - t[2 + 3 * J], t[4 + 3 * J] - t[3 + 3 * J]);
   printf(" | logdet+inverse %lld publish %lld barrier %lld | factor total %lld cycles (100 MHz ticks if clock64 is the fixed counter)\n", t[21] - t[20], t[22] - t[21], t[23] - t[22], t[22] - t[0]);
+  printf("wavefront 1 tiles (cycles from the barrier):");
+  for (int i = 0; i < 9; ++i) printf(" | #%d start %lld mfma-done %lld out %lld staged-next %lld", i, t[24 + 4 * i] - t[23], t[25 + 4 * i] - t[23], t[26 + 4 * i] - t[23], t[27 + 4 * i] - t[23]);
+  printf("\n");
   return 0;
 }
