@@ -114,40 +114,81 @@ M355_DEV void normal_pair(double u1, double u2, double& z0, double& z1) {
 
 constexpr int kMaxAttempts = 256;  // P(no acceptance) < 1e-50 for every sampler below
 
-// Gamma(shape a, scale 1), Marsaglia & Tsang (2000).  a == 0 -> 0; a < 0 or NaN -> NaN.
+// cos(2 pi (w + 1/2) 2^-32) for a 32-bit word w: the quadrant is the top two bits, the position in it the other 30 (exact
+// integer reduction); cos and sin of the quarter period are ONE polynomial, cos(pi rho / 2) on (0, 1), read forwards or
+// backwards (rho -> 1 - rho is the bit complement).  Taylor in rho^2 to (pi/2)^20 / 20! (truncation 1.8e-17 absolute).
+M355_HD double cos_2pi_u32(unsigned w) {
+  const unsigned q = w >> 30;
+  unsigned f = w & 0x3fffffffu;
+  if (q & 1u) f = 0x3fffffffu - f;
+  const double rho = ((double)f + 0.5) * 0x1.0p-30;
+  const double t = rho * rho;
+  double p = sconst(3.43773917909860700022e-15);
+  p = __builtin_fma(p, t, sconst(-5.29440020073462376193e-13));
+  p = __builtin_fma(p, t, sconst(6.56596311497947236221e-11));
+  p = __builtin_fma(p, t, sconst(-6.38660308379185224109e-9));
+  p = __builtin_fma(p, t, sconst(4.71087477881817150367e-7));
+  p = __builtin_fma(p, t, sconst(-0.0000252020423730606054811));
+  p = __builtin_fma(p, t, sconst(0.000919260274839426580242));
+  p = __builtin_fma(p, t, sconst(-0.0208634807633529608731));
+  p = __builtin_fma(p, t, sconst(0.253669507901048013637));
+  p = __builtin_fma(p, t, sconst(-1.23370055013616982735));
+  p = __builtin_fma(p, t, 1.0);
+  return ((q + 1u) & 2u) ? -p : p;
+}
+
+// ONE standard normal from three words of a Philox block (single-output Box-Muller): the radius from the 52-bit uniform
+// of words 0-1, the angle from the 32 bits of word 2 -- the draw is continuous in the radius, so a 2^-32 grid of angles
+// costs no resolution -- which leaves word 3 to the caller (the acceptance uniform of a rejection sampler).
+M355_DEV double normal_single(const Philox& p) {
+  return fsqrt(-2.0 * flog_tab(u53(p.c[0], p.c[1]))) * cos_2pi_u32(p.c[2]);
+}
+
+// Uniform in (0, 1) on a 2^-44 grid from word 3 and the twelve low bits of word 0 that u53 drops (mantissa trick as in
+// u53; the forced low bit keeps it off 0: log(u) is finite).
+M355_HD double u44(unsigned w3, unsigned w0) {
+  const unsigned long long bits = ((unsigned long long)(0x3ff00000u | (w3 >> 12)) << 32) |
+                                  (unsigned long long)((w3 << 20) | ((w0 & 0xfffu) << 8) | 0x80u);
+  return __builtin_bit_cast(double, bits) - 1.0;
+}
+
+// Gamma(shape a >= 1, scale 1), Marsaglia & Tsang (2000): the shape-only constants and ONE attempt from ONE Philox block
+// (normal from words 0-2, acceptance uniform from word 3).  Shared by the per-lane loop (sample_std_gamma) and the
+// compacting kernel (k_rvs_mt), so both produce the same draw for the same (element, attempt) counters.
+struct MtK {
+  double d, c;
+};
+M355_DEV MtK mt_setup(double a) {
+  MtK k;
+  k.d = a - 1.0 / 3.0;
+  k.c = 1.0 / (3.0 * fsqrt(k.d));
+  return k;
+}
+M355_DEV bool mt_attempt(const MtK& k, const Philox& p, double& g, double& x) {
+  x = normal_single(p);
+  const double u = u44(p.c[3], p.c[0]);
+  const double t = 1.0 + k.c * x;
+  const double vv = t * t * t;
+  const double x2 = x * x;
+  g = k.d * vv;
+  if (!(t > 0.0)) return false;
+  return u < 1.0 - 0.0331 * x2 * x2 || flog_tab(u) < 0.5 * x2 + k.d * (1.0 - vv + flog_tab(vv));
+}
+
+// Gamma(shape a, scale 1).  a == 0 -> 0; a < 0 or NaN -> NaN.  a < 1: Gamma(a + 1) U^(1/a), one more block.
 M355_DEV double sample_std_gamma(RngState& st, double a) {
   if (!(a >= 0.0)) return kNaN;
   if (a == 0.0) return 0.0;
   if (a == kInf) return kInf;
   const bool boost = a < 1.0;
-  const double aa = boost ? a + 1.0 : a;
-  const double d = aa - 1.0 / 3.0;
-  const double c = 1.0 / (3.0 * fsqrt(d));
-  double v = 1.0;
+  const MtK k = mt_setup(boost ? a + 1.0 : a);
+  double g = k.d;
   for (int it = 0; it < kMaxAttempts; ++it) {
-    double u1, u2, u3, u4;
-    next_pair(st, u1, u2);
-    next_pair(st, u3, u4);
-    double x0, x1;
-    normal_pair(u1, u2, x0, x1);
-    // two candidates per normal pair
-    bool ok = false;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const double x = j == 0 ? x0 : x1;
-      const double u = j == 0 ? u3 : u4;
-      const double t = 1.0 + c * x;
-      if (ok || !(t > 0.0)) continue;
-      const double vv = t * t * t;
-      const double x2 = x * x;
-      if (u < 1.0 - 0.0331 * x2 * x2 || flog_tab(u) < 0.5 * x2 + d * (1.0 - vv + flog_tab(vv))) {
-        v = vv;
-        ok = true;
-      }
-    }
-    if (ok) break;
+    const Philox p = philox4x32_10(st.idx_lo, st.idx_hi, st.attempt, st.stream, st.k0, st.k1);
+    st.attempt += 1;
+    double x;
+    if (mt_attempt(k, p, g, x)) break;
   }
-  double g = d * v;
   if (boost) {
     double u1, u2;
     next_pair(st, u1, u2);
@@ -343,9 +384,9 @@ template <int D> M355_DEV double sample_one(unsigned long long idx, unsigned lon
     const double gb = sample_std_gamma(st, p[1]);
     return ga / (ga + gb);
   } else if constexpr (D == M355_STUDENTT) {  // studentt.py:96-97: mu + sigma * z / sqrt(chi2_nu / nu)
-    double u1, u2, z0, z1;
-    next_pair(st, u1, u2);
-    normal_pair(u1, u2, z0, z1);
+    const Philox b0 = philox4x32_10(st.idx_lo, st.idx_hi, 0u, st.stream, st.k0, st.k1);
+    st.attempt = 1;
+    const double z0 = normal_single(b0);
     const double g = sample_std_gamma(st, 0.5 * p[0]);  // chi2_nu / 2
     return p[1] + p[2] * z0 * fsqrt(0.5 * p[0] / g);
   } else if constexpr (D == M355_POISSON) {  // poisson.py:66-67

@@ -107,6 +107,132 @@ __global__ __launch_bounds__(kBlock) void k_rvs_compact(void* __restrict__ out, 
   }
 }
 
+// Marsaglia-Tsang samplers with the same wavefront-level compaction (scalar parameters, every gamma shape >= 1): gamma and
+// its one-gamma relatives, beta / betascaled (two gammas: stage 0 then stage 1 with the other shape's constants -- the
+// same code), Student t (stage 0 keeps the normal of block 0, stage 1 is the gamma of shape nu / 2).  One Philox block
+// and one attempt per lane per round; a lane that finishes its element takes the next one of the chunk.  Attempt
+// numbers run on across the stages exactly as in sample_one's per-lane loops: the output is identical to k_rvs.
+template <int D> struct MtPlan;  // stages, shapes and the last step of sample_one<D>
+template <> struct MtPlan<M355_GAMMA> {
+  static constexpr int kStages = 1;
+  static M355_HD double shape(const double* p, int) { return p[0]; }
+  static M355_DEV double finish(const double* p, double, double g) { return g / p[1]; }
+};
+template <> struct MtPlan<M355_INVERSEGAMMA> {
+  static constexpr int kStages = 1;
+  static M355_HD double shape(const double* p, int) { return p[0]; }
+  static M355_DEV double finish(const double* p, double, double g) { return p[1] / g; }
+};
+template <> struct MtPlan<M355_CHISQUARED> {
+  static constexpr int kStages = 1;
+  static M355_HD double shape(const double* p, int) { return 0.5 * p[0]; }
+  static M355_DEV double finish(const double*, double, double g) { return 2.0 * g; }
+};
+template <> struct MtPlan<M355_SCALEDINVERSECHISQUARED> {
+  static constexpr int kStages = 1;
+  static M355_HD double shape(const double* p, int) { return 0.5 * p[0]; }
+  static M355_DEV double finish(const double* p, double, double g) { return (p[0] * p[1]) / (2.0 * g); }
+};
+template <> struct MtPlan<M355_BETA> {
+  static constexpr int kStages = 2;
+  static M355_HD double shape(const double* p, int st) { return p[st]; }
+  static M355_DEV double finish(const double*, double ga, double gb) { return ga / (ga + gb); }
+};
+template <> struct MtPlan<M355_BETASCALED> {
+  static constexpr int kStages = 2;
+  static M355_HD double shape(const double* p, int st) { return p[st]; }
+  static M355_DEV double finish(const double* p, double ga, double gb) { return ga / (ga + gb) * (p[3] - p[2]) + p[2]; }
+};
+template <> struct MtPlan<M355_STUDENTT> {
+  static constexpr int kStages = 2;  // stage 0: the normal (always accepted)
+  static M355_HD double shape(const double* p, int) { return 0.5 * p[0]; }
+  static M355_DEV double finish(const double* p, double z0, double g) { return p[1] + p[2] * z0 * fsqrt(0.5 * p[0] / g); }
+};
+
+struct MtParams {
+  double p[kMaxParams];
+};
+
+template <int D>
+__global__ __launch_bounds__(kBlock) void k_rvs_mt(void* __restrict__ out, int odt, long long n, const MtParams pa,
+                                                   unsigned long long seed, unsigned stream, unsigned long long offset) {
+  using Plan = MtPlan<D>;
+  log_table_init();
+  const long long wave = (long long)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  const long long nwaves = (long long)gridDim.x * (kBlock / 64);
+  const long long chunk = ((n + nwaves - 1) / nwaves + 63) & ~63ll;
+  const long long w1 = (wave + 1) * chunk < n ? (wave + 1) * chunk : n;
+  long long next = wave * chunk;  // wave-uniform: first unassigned element
+  if (next >= w1) return;
+  const MtK k0 = mt_setup(Plan::shape(pa.p, 0));
+  const MtK k1 = mt_setup(Plan::shape(pa.p, Plan::kStages - 1));
+  long long idx = -1;  // element held by this lane (-1: none)
+  unsigned attempt = 0;
+  int stage = 0;
+  double hold = 0.0;  // the first stage's result
+  for (;;) {
+    const bool freed = idx < 0;
+    const unsigned long long fm = __ballot(freed);
+    const unsigned below = __builtin_amdgcn_mbcnt_hi((unsigned)(fm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)fm, 0u));
+    if (freed) {
+      const long long cand = next + below;
+      if (cand < w1) {
+        idx = cand;
+        attempt = 0;
+        stage = 0;
+      }
+    }
+    next += __popcll(fm);
+    if (next > w1) next = w1;
+    const bool active = idx >= 0;
+    if (__ballot(active) == 0ull) break;  // chunk exhausted and every lane has stored its draw
+    if (active) {
+      const unsigned long long c = offset + (unsigned long long)idx;
+      const Philox ph = philox4x32_10((unsigned)c, (unsigned)(c >> 32), attempt, stream, (unsigned)seed, (unsigned)(seed >> 32));
+      attempt += 1;
+      MtK kk;
+      kk.d = stage == 0 ? k0.d : k1.d;
+      kk.c = stage == 0 ? k0.c : k1.c;
+      double g, x;
+      bool ok = mt_attempt(kk, ph, g, x);
+      if constexpr (D == M355_STUDENTT) {
+        if (stage == 0) {
+          ok = true;
+          g = x;
+        }
+      }
+      if (ok || attempt >= (unsigned)kMaxAttempts) {
+        if (stage + 1 < Plan::kStages) {
+          hold = g;
+          stage = 1;
+        } else {
+          store_draw(out, odt, idx, Plan::finish(pa.p, hold, g));
+          idx = -1;
+        }
+      }
+    }
+  }
+}
+
+template <int D> bool try_rvs_mt(const GenericOps& ops, void* out, int odt, long long n, unsigned long long seed,
+                                 unsigned stream, unsigned long long offset, hipStream_t s, int* rc) {
+  if (n < 4096) return false;
+  MtParams pa{};
+  for (int q = 0; q < Dist<D>::NP; ++q) {
+    if (ops.p[q].ptr != nullptr) return false;
+    pa.p[q] = ops.p[q].scalar;
+  }
+  for (int st = 0; st < MtPlan<D>::kStages; ++st) {
+    const double a = MtPlan<D>::shape(pa.p, st);
+    if (!(a >= 1.0) || !(a < kInf)) return false;  // (a < 1 takes a boost block after the accepted attempt: per-lane loop)
+  }
+  const long long want = (n + 4 * kBlock - 1) / (4 * kBlock);  // >= 256 elements per wavefront
+  const int blocks = (int)(want > 8192 ? 8192 : want);
+  hipLaunchKernelGGL((k_rvs_mt<D>), dim3(blocks), dim3(kBlock), 0, s, out, odt, n, pa, seed, stream, offset);
+  *rc = (int)hipGetLastError();
+  return true;
+}
+
 template <int D> int launch_rvs(const GenericOps& ops, void* out, int odt, long long n, unsigned long long seed,
                                 unsigned stream, unsigned long long offset, hipStream_t s) {
   const long long want = (n + kBlock - 1) / kBlock;
@@ -148,6 +274,23 @@ extern "C" int m355_rvs_impl(int dist, int out_dtype, long long n, const m355::G
       hipLaunchKernelGGL((k_rvs_compact<M355_BINOMIAL>), dim3(blocks), dim3(kBlock), 0, s, out, out_dtype, n, q0, q1, seed,
                          stream_id, offset);
     return (int)hipGetLastError();
+  }
+  {
+    int rc = 0;
+    bool done = false;
+    switch (dist) {
+      case M355_GAMMA: done = try_rvs_mt<M355_GAMMA>(*ops, out, out_dtype, n, seed, stream_id, offset, s, &rc); break;
+      case M355_INVERSEGAMMA: done = try_rvs_mt<M355_INVERSEGAMMA>(*ops, out, out_dtype, n, seed, stream_id, offset, s, &rc); break;
+      case M355_CHISQUARED: done = try_rvs_mt<M355_CHISQUARED>(*ops, out, out_dtype, n, seed, stream_id, offset, s, &rc); break;
+      case M355_SCALEDINVERSECHISQUARED:
+        done = try_rvs_mt<M355_SCALEDINVERSECHISQUARED>(*ops, out, out_dtype, n, seed, stream_id, offset, s, &rc);
+        break;
+      case M355_BETA: done = try_rvs_mt<M355_BETA>(*ops, out, out_dtype, n, seed, stream_id, offset, s, &rc); break;
+      case M355_BETASCALED: done = try_rvs_mt<M355_BETASCALED>(*ops, out, out_dtype, n, seed, stream_id, offset, s, &rc); break;
+      case M355_STUDENTT: done = try_rvs_mt<M355_STUDENTT>(*ops, out, out_dtype, n, seed, stream_id, offset, s, &rc); break;
+      default: break;
+    }
+    if (done) return rc;
   }
   switch (dist) {
 #define M355_RVS_CASE(ID, name, np) \

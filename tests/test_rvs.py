@@ -263,6 +263,28 @@ def test_gpu_compaction_equals_per_lane_loop(gpu, name, params):
     assert np.array_equal(a, c)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("name, params", [("gamma", (2.5, 1.3)), ("gamma", (1.0, 2.0)), ("beta", (2.0, 5.0)),
+                                          ("studentt", (5.0, 0.0, 2.0)), ("chisquared", (7.0,)), ("inversegamma", (3.0, 2.0)),
+                                          ("scaledinversechisquared", (4.0, 1.5)), ("betascaled", (2.0, 3.0, -1.0, 4.0))])
+def test_gpu_marsaglia_tsang_compaction_equals_per_lane_loop(gpu, name, params):
+    """k_rvs_mt (scalar parameters, shapes >= 1: one Philox block per attempt, lanes refilled as they finish) and the
+    per-lane loop of k_rvs (array parameters) give bit-identical draws, for any split of the range over calls."""
+    import importlib
+
+    m = importlib.import_module(f"distributions_amd.{name}")
+    n = 300_007
+    a = m.rvs(*params, size=n, random_state=12)
+    arr = [np.full(n, p, dtype=np.float64) for p in params]
+    b = m.rvs(*arr, size=n, random_state=12)
+    assert a.dtype == np.float64 and np.array_equal(a, b)
+    h = 123_457
+    c = np.concatenate([m.rvs(*params, size=h, random_state=(12, 0)), m.rvs(*params, size=n - h, random_state=(12, h))])
+    assert np.array_equal(a, c)
+    small = m.rvs(*params, size=1000, random_state=(12, 0))  # (below the kernel's threshold: the per-lane loop)
+    assert np.array_equal(a[:1000], small)
+
+
 FAMILY_RVS = [
     ("exponential", (0.27,), lambda: stats.expon(scale=1 / 0.27)),
     ("lognormal", (2.0, 0.5), lambda: stats.lognorm(s=0.5, scale=np.exp(2.0))),
