@@ -66,6 +66,39 @@ M355_DEV double readlane_d(double v, int lane) {  // `lane` must be wave-uniform
   return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
 }
 
+// u += (lane N of the caller's row of 16 lanes of r) * m: ONE instruction (v_fmac_f64 with the DPP control row_newbcast,
+// gfx90a+), where a v_readlane broadcast costs two instructions plus the FMA.  r must not come out of a VALU
+// instruction in the two preceding slots (DPP read hazard): here it is an LDS return (ds_bpermute).
+template <int N> M355_DEV void fmac_row_bcast(double& u, double r, double m) {
+  asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(u) : "v"(r), "v"(m), "n"(N));
+}
+M355_DEV void fmac_row_bcast_n(double& u, double r, double m, int n) {  // n: a constant after unrolling
+  switch (n) {
+    case 1: fmac_row_bcast<1>(u, r, m); break;
+    case 2: fmac_row_bcast<2>(u, r, m); break;
+    case 3: fmac_row_bcast<3>(u, r, m); break;
+    case 4: fmac_row_bcast<4>(u, r, m); break;
+    case 5: fmac_row_bcast<5>(u, r, m); break;
+    case 6: fmac_row_bcast<6>(u, r, m); break;
+    case 7: fmac_row_bcast<7>(u, r, m); break;
+    case 8: fmac_row_bcast<8>(u, r, m); break;
+    case 9: fmac_row_bcast<9>(u, r, m); break;
+    case 10: fmac_row_bcast<10>(u, r, m); break;
+    case 11: fmac_row_bcast<11>(u, r, m); break;
+    case 12: fmac_row_bcast<12>(u, r, m); break;
+    case 13: fmac_row_bcast<13>(u, r, m); break;
+    case 14: fmac_row_bcast<14>(u, r, m); break;
+    default: fmac_row_bcast<15>(u, r, m); break;
+  }
+}
+// v of lane (byte address addr4 / 4), any lane pattern, through the LDS crossbar (no LDS memory, no VALU slot)
+M355_DEV double bpermute_d(int addr4, double v) {
+  const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+  const unsigned lo = (unsigned)__builtin_amdgcn_ds_bpermute(addr4, (int)(unsigned)b);
+  const unsigned hi = (unsigned)__builtin_amdgcn_ds_bpermute(addr4, (int)(unsigned)(b >> 32));
+  return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+
 // sqrt(a) and 1/sqrt(a) from the hardware rsq seed (coupled Newton steps, ~1 ulp each); a <= 0 or
 // NaN gives NaN for both (a non-positive pivot poisons the factor, as the reference's does).
 // (CHECKED = false leaves out the final selects: a < 0 and NaN give NaN through v_rsq_f64 itself, a = 0 and a = inf
@@ -310,8 +343,14 @@ __global__ __launch_bounds__(kCholThreads) void k_cholesky(const double* __restr
 // costs five operations per column.  Finished rows (lanes < 16J + c) keep computing on values nobody reads: no selects.
 // LDS 8.7 KiB per wavefront (k_mvn_batched of round 2 kept the matrix in LDS: 33 KiB, four wavefronts per CU, 52 us per
 // matrix in a chain of LDS round trips).
+#ifndef M355_TILES_DPP
+#define M355_TILES_DPP 1
+#endif
+#ifndef M355_TILES_WAVES
+#define M355_TILES_WAVES 3  // wavefronts per SIMD the register budget is set for (4 spills 16 VGPRs at d = 64 and is no faster)
+#endif
 template <int NB>
-__global__ __launch_bounds__(64, 3) void k_mvn_tiles(const double* __restrict__ cov, int d, const FusedArgs fa) {
+__global__ __launch_bounds__(64, M355_TILES_WAVES) void k_mvn_tiles(const double* __restrict__ cov, int d, const FusedArgs fa) {
   __shared__ double P[64 * 17];
   const int lane = threadIdx.x, r16 = lane & 15, g = lane >> 4;
   const int prow = lane < 16 * NB ? lane : 16 * NB - 1;  // (NB < 4: the lanes past the matrix shadow its last row)
@@ -364,7 +403,7 @@ __global__ __launch_bounds__(64, 3) void k_mvn_tiles(const double* __restrict__ 
       for (int kk = 0; kk < 4; ++kk) P[(16 * I + r16) * 17 + g + 4 * kk] = T[I][J][kk];
     }
     __syncthreads();
-    double u[16], l[16];
+    double u[16];
 #pragma unroll
     for (int c = 0; c < 16; ++c) u[c] = P[prow * 17 + c];
 #pragma unroll
@@ -372,11 +411,21 @@ __global__ __launch_bounds__(64, 3) void k_mvn_tiles(const double* __restrict__ 
       double piv, rinv;
       sqrt_rsqrt<false>(readlane_d(u[c], 16 * J + c), piv, rinv);
       const double lc = u[c] * rinv;
-      l[c] = lc;
-      if (lane == 16 * J + c) mydiag = piv;
+      P[lane * 17 + c] = lc;  // (row layout, for the trailing tiles and the diagonal; the panel's values are all in u by now)
       const double yc = readlane_d(bcur, 16 * J + c) * rinv;
       quad = __builtin_fma(yc, yc, quad);
       bcur = __builtin_fma(-yc, lc, bcur);
+#if M355_TILES_DPP
+      // the multipliers L[16J + c2][c] sit in the lanes of row group J: one ds_bpermute pair copies that group's l_c into
+      // every group of 16 lanes, and each update is then a single v_fmac_f64 whose first operand is lane c2 of the
+      // caller's own row (DPP row_newbcast) -- 1 instruction per update where a v_readlane broadcast took 3
+      if (c < 15) {
+        const double rep = bpermute_d(4 * (16 * J + r16), lc);
+        const double nlc = -lc;
+#pragma unroll
+        for (int c2 = c + 1; c2 < 16; ++c2) fmac_row_bcast_n(u[c2], rep, nlc, c2);
+      }
+#else
       // multipliers four at a time: a v_readlane result needs two wait states before a VALU reads it, which the
       // next broadcasts fill (one pair at a time the compiler reuses one SGPR pair and pads every FMA with s_nop)
 #pragma unroll
@@ -390,14 +439,15 @@ __global__ __launch_bounds__(64, 3) void k_mvn_tiles(const double* __restrict__ 
         }
         __builtin_amdgcn_sched_barrier(0);
       }
+#endif
     }
     {
+      // the sweep left the panel in LDS in row layout (no registers for it: 116 VGPRs, four wavefronts per SIMD):
+      // lane i's own diagonal entry L_ii is read back from there (a select per column cost three instructions each), and
+      // the tiles under the diagonal one return to the A layout
+      __syncthreads();
+      if (g == J) mydiag = P[lane * 17 + r16];
       if (J + 1 < NB) {
-        // the tiles under the diagonal one go back to the A layout for the trailing updates
-        __syncthreads();
-#pragma unroll
-        for (int c = 0; c < 16; ++c) P[lane * 17 + c] = l[c];
-        __syncthreads();
         d4_t L[NB];
 #pragma unroll
         for (int I = J + 1; I < NB; ++I) {
