@@ -155,6 +155,10 @@ def _build_operands(pl: Plan, args: Sequence[Any], torch, device):
 # row-periodic ones
 TABLE_DISTS = ("gamma", "beta", "studentt", "halfstudentt", "chisquared", "inversegamma", "scaledinversechisquared",
                "betascaled")
+# discrete families whose cdf / sf / logcdf / logsf with row-periodic parameters are looked up in per-column windows of
+# exact values (k_dcol: 2 + 2048 doubles per column), from 8 x the table threshold (2**24 elements by default)
+DTABLE_DISTS = ("poisson", "binomial", "negativebinomial", "betabinomial", "hypergeometric", "zi_poisson", "zi_binomial",
+                "zi_negativebinomial")
 _TABLE_WS_MAX = 1 << 30
 
 
@@ -171,6 +175,9 @@ def _table_workspace(dist: str, fn: str, pl: Plan, torch, device):
             return None  # not row-periodic: the library's generic kernel
         period = int(op.mod)
     densities = fn in ("logpdf", "pdf")
+    if period and dist in DTABLE_DISTS and fn in ("cdf", "sf", "logcdf", "logsf") and pl.n >= 8 * int(_lib.lib().m355_tab_min_n()):
+        need = int(_lib.lib().m355_elemwise_workspace_bytes_for(pl.n, period))
+        return torch.empty(need, dtype=torch.uint8, device=device) if 0 < need <= _TABLE_WS_MAX else None
     if period == 0 and (densities or dist not in TABLE_DISTS):
         return None
     if period and (densities or dist not in TABLE_DISTS):

@@ -126,6 +126,8 @@ def lib():
     L.m355_sumlogp_static_max_n.restype = i64
     L.m355_set_tab_min_n.restype = i64
     L.m355_set_tab_min_n.argtypes = [i64]
+    L.m355_tab_min_n.restype = i64
+    L.m355_tab_min_n.argtypes = []
     L.m355_sumlogp_static.restype = i32
     L.m355_sumlogp_static.argtypes = [i32, i32, i64, op, i32, op, vp, vp]
     L.m355_rvs.restype = i32

@@ -150,6 +150,10 @@ size_t m355_elemwise_workspace_bytes_for(int64_t n, int64_t period) {
   // the derived constants of the P parameter sets (k_periodic_fixed: stored logpdf / pdf), and, for periods the table
   // kernels take, the per-column tables and miss words of logcdf / logsf / cdf / sf / ppf / isf
   size_t need = (size_t)period * 16 * sizeof(double);
+  {  // the discrete families' windows (k_dcol): two header doubles and up to kDTabMax values per column
+    const size_t t = ((size_t)period * (2 + (size_t)m355::kDTabMax) + m355::kDColHdr) * sizeof(double);
+    need = t > need ? t : need;
+  }
   if (period % m355::kCtCols == 0) {
     const size_t t = m355::coltab_ws_doubles<M355_LOGCDF>((unsigned long long)period, (long long)(n / period)) * sizeof(double);
     need = t > need ? t : need;
@@ -256,6 +260,8 @@ int static_scratch(double** out) {
 extern "C" {
 
 int64_t m355_sumlogp_static_max_n(void) { return M355_SUMLOGP_STATIC_MAX_N; }
+
+int64_t m355_tab_min_n(void) { return m355::tab_min_n_ref().load(); }
 
 int64_t m355_set_tab_min_n(int64_t min_n) {
   return m355::tab_min_n_ref().exchange(min_n < 0 ? m355::kTabMinN : (long long)min_n);

@@ -599,7 +599,7 @@ template <> struct Dist<M355_POISSON> {
     return (xlogy0_l(x, k.logmu) - lgamma1p_obs(x)) - k.mu;
   }
   // k_dtab (m355_elemwise.h): window of integers for the cdf family
-  static bool dtab_range(const K& k, double& lo, int& len) { return dtab_window(k.mu, sqrt(k.mu), 0.0, kInf, lo, len); }
+  static M355_HD bool dtab_range(const K& k, double& lo, int& len) { return dtab_window(k.mu, sqrt(k.mu), 0.0, kInf, lo, len); }
   static M355_DEV double cdf(double x, const K& k) {  // poisson.py:49-50
     return cdf_bounds(gammainc_q(x + 1.0, k.mu, lgamma_(x + 1.0)), x, 0.0, kInf);
   }
@@ -658,7 +658,7 @@ template <> struct Dist<M355_BINOMIAL> {
     return ((x < 0.0) | (x > k.n)) ? -kInf : r;
   }
   static M355_DEV double logpdf(double x, const K& k) { return logpdf_t<false>(x, k); }
-  static bool dtab_range(const K& k, double& lo, int& len) {
+  static M355_HD bool dtab_range(const K& k, double& lo, int& len) {
     return dtab_window(k.n * k.p, sqrt(k.n * k.p * (1.0 - k.p)), 0.0, k.n, lo, len);
   }
   static M355_DEV double cdf(double x, const K& k) {  // binomial.py:45-46

@@ -136,7 +136,7 @@ template <> struct Dist<M355_NEGATIVEBINOMIAL> {
   static constexpr int kBinned = 1;
   static constexpr int NP = 2;
   using K = NegBinK;
-  static bool dtab_range(const K& k, double& lo, int& len) {
+  static M355_HD bool dtab_range(const K& k, double& lo, int& len) {
     return dtab_window(k.n * (1.0 - k.p) / k.p, sqrt(k.n * (1.0 - k.p)) / k.p, 0.0, kInf, lo, len);
   }
   static M355_HD K derive(const double* p) { return negbin_derive(p[0], p[1]); }
@@ -166,7 +166,7 @@ template <> struct Dist<M355_BETABINOMIAL> {
   static constexpr int kBinned = 1;
   static constexpr int NP = 3;
   struct K { double n, a, b, c; };  // c: the x-independent gammaln terms
-  static bool dtab_range(const K& k, double& lo, int& len) {  // the whole support when it fits, else around the mean
+  static M355_HD bool dtab_range(const K& k, double& lo, int& len) {  // the whole support when it fits, else around the mean
     const double m = k.n * k.a / (k.a + k.b);
     const double v = m * k.b / (k.a + k.b) * (k.a + k.b + k.n) / (k.a + k.b + 1.0);
     return dtab_window(m, k.n < (double)kDTabMax ? k.n : sqrt(v), 0.0, k.n, lo, len);
@@ -214,7 +214,7 @@ template <> struct Dist<M355_HYPERGEOMETRIC> {
   static constexpr int kBinned = 1;
   static constexpr int NP = 3;
   struct K { double N, k, n, lo, hi, lbNn, lgk1, lgNk1; };
-  static bool dtab_range(const K& k, double& lo, int& len) {
+  static M355_HD bool dtab_range(const K& k, double& lo, int& len) {
     const double m = k.n * k.k / k.N;
     return dtab_window(m, sqrt(m * (1.0 - k.k / k.N)), k.lo, k.hi, lo, len);
   }
@@ -270,7 +270,7 @@ template <> struct Dist<M355_ZI_POISSON> {
   static constexpr int kBinned = 1;
   static constexpr int NP = 2;
   struct K { double psi, logpsi, log_zero; Dist<M355_POISSON>::K b; };
-  static bool dtab_range(const K& k, double& lo, int& len) {  // the base distribution's window, down to 0
+  static M355_HD bool dtab_range(const K& k, double& lo, int& len) {  // the base distribution's window, down to 0
     return dtab_window(0.5 * k.b.mu, 0.5 * k.b.mu / 9.0 + sqrt(k.b.mu), 0.0, kInf, lo, len);
   }
   static M355_HD K derive(const double* p) {
@@ -315,7 +315,7 @@ template <> struct Dist<M355_ZI_BINOMIAL> {
   static constexpr int kBinned = 1;
   static constexpr int NP = 3;
   struct K { double psi, logpsi, log_zero; Dist<M355_BINOMIAL>::K b; };
-  static bool dtab_range(const K& k, double& lo, int& len) {
+  static M355_HD bool dtab_range(const K& k, double& lo, int& len) {
     const double m = k.b.n * k.b.p;
     return dtab_window(0.5 * m, 0.5 * m / 9.0 + sqrt(m * (1.0 - k.b.p)), 0.0, k.b.n, lo, len);
   }
@@ -358,7 +358,7 @@ template <> struct Dist<M355_ZI_NEGATIVEBINOMIAL> {
   static constexpr int kBinned = 1;
   static constexpr int NP = 3;
   struct K { double psi, logpsi, log_zero; NegBinK b; };
-  static bool dtab_range(const K& k, double& lo, int& len) {
+  static M355_HD bool dtab_range(const K& k, double& lo, int& len) {
     const double m = k.b.n * (1.0 - k.b.p) / k.b.p;
     return dtab_window(0.5 * m, 0.5 * m / 9.0 + sqrt(k.b.n * (1.0 - k.b.p)) / k.b.p, 0.0, kInf, lo, len);
   }

@@ -1657,6 +1657,126 @@ __global__ __launch_bounds__(kBlock) void k_dtab_ppf(const void* __restrict__ x,
   }
 }
 
+// The same lookup with row-periodic parameters (x of shape (R, P), parameters (P,)): one window per column, built ONCE per
+// call into the caller's workspace (m355_elemwise_ws) and read back through L2 by k_dcol.  Workspace (doubles):
+// [0] the longest window of the call (an int, atomicMax: the tables' common stride, so that they stay as compact as the
+// data allows -- 1024 windows of ~300 values are 2.4 MB, L2-resident, where a fixed stride of 2048 made them 16 MB);
+// [8 + 2p] lo, [8 + 2p + 1] len of column p (-1: no table: the window does not fit, or the parameters are out of domain);
+// then tab[p * stride + j] = the exact body at lo + j.  A thread of k_dcol meets the same kUnroll * kVec columns in every
+// tile (the launcher makes gridDim.x * kTile a multiple of P, as for k_periodic_fixed), keeps their windows in registers,
+// and a lookup is one 8-byte gather.  The looked-up value IS the exact body's value: bit-identical to k_periodic.
+constexpr int kDColHdr = 8;
+template <int D>
+__global__ __launch_bounds__(kBlock) void k_dcol_ranges(PeriodicParams pa, unsigned P, unsigned max_stride, double* __restrict__ ws) {
+  using DD = Dist<D>;
+  const unsigned p = blockIdx.x * kBlock + threadIdx.x;
+  if (p >= P) return;
+  double pp[kMaxParams];
+#pragma unroll
+  for (int q = 0; q < kMaxParams; ++q) pp[q] = (q < DD::NP && pa.ptr[q]) ? pa.ptr[q][p] : pa.scalar[q];
+  const typename DD::K k = DD::derive(pp);
+  double lo = 0.0;
+  int len = 0;
+  const bool ok = DD::dtab_range(k, lo, len) && len <= (int)max_stride;
+  ws[kDColHdr + 2 * (size_t)p] = ok ? lo : 0.0;
+  ws[kDColHdr + 2 * (size_t)p + 1] = ok ? (double)len : -1.0;
+  if (ok) atomicMax(reinterpret_cast<int*>(ws), len);
+}
+template <int D, int FN>
+__global__ __launch_bounds__(kBlock) void k_dcol_build(PeriodicParams pa, unsigned P, unsigned max_stride, double* __restrict__ ws) {
+  using DD = Dist<D>;
+  const unsigned chunks = (max_stride + kBlock - 1) / kBlock;
+  const unsigned p = blockIdx.x / chunks, ch = blockIdx.x % chunks;
+  const int len = (int)ws[kDColHdr + 2 * (size_t)p + 1];
+  if ((int)(ch * kBlock) >= len) return;  // (workgroup-uniform)
+  if constexpr (uses_log_table<DD>::value) log_table_init();
+  const unsigned stride = (unsigned)*reinterpret_cast<const int*>(ws);
+  const double lo = ws[kDColHdr + 2 * (size_t)p];
+  double pp[kMaxParams];
+#pragma unroll
+  for (int q = 0; q < kMaxParams; ++q) pp[q] = (q < DD::NP && pa.ptr[q]) ? pa.ptr[q][p] : pa.scalar[q];
+  const typename DD::K k = DD::derive(pp);
+  const int j = (int)(ch * kBlock + threadIdx.x);
+  if (j < len) ws[kDColHdr + 2 * (size_t)P + (size_t)p * stride + j] = DD::template eval<FN>(lo + (double)j, k);
+}
+template <int D, int FN>
+__device__ __noinline__ double dcol_exact(double x, const PeriodicParams& pa, unsigned col) {
+  using DD = Dist<D>;
+  double pp[kMaxParams];
+#pragma unroll
+  for (int q = 0; q < kMaxParams; ++q) pp[q] = (q < DD::NP && pa.ptr[q]) ? pa.ptr[q][col] : pa.scalar[q];
+  return DD::template eval<FN>(x, DD::derive(pp));
+}
+template <int D, int FN>
+__global__ __launch_bounds__(kBlock) void k_dcol(const void* __restrict__ x, int xdt, void* __restrict__ out, int odt, long long n,
+                                                 unsigned P, PeriodicParams pa, const double* __restrict__ ws) {
+  using DD = Dist<D>;
+  if constexpr (uses_log_table<DD>::value) log_table_init();
+  const unsigned stride = (unsigned)*reinterpret_cast<const int*>(ws);
+  const double* hdr = ws + kDColHdr;
+  const double* tab = hdr + 2 * (size_t)P;
+  const long long ntiles = n / kTile;
+  double clo[kUnroll][kVec], clen[kUnroll][kVec];
+  unsigned ccol[kUnroll][kVec];
+  {
+    unsigned idx = (unsigned)(((unsigned long long)blockIdx.x * kTile + threadIdx.x * kVec) % P);
+    const unsigned u_step = (unsigned)((kBlock * kVec) % P);
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) {
+      unsigned idx1 = idx + 1;
+      idx1 = idx1 >= P ? idx1 - P : idx1;
+      ccol[u][0] = idx;
+      ccol[u][1] = idx1;
+#pragma unroll
+      for (int q = 0; q < kVec; ++q) {
+        clo[u][q] = hdr[2 * (size_t)ccol[u][q]];
+        clen[u][q] = hdr[2 * (size_t)ccol[u][q] + 1];
+      }
+      idx += u_step;
+      idx = idx >= P ? idx - P : idx;
+    }
+  }
+  for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const long long base = tile * kTile + threadIdx.x * kVec;
+    double v[kUnroll][kVec], r[kUnroll][kVec];
+    bool ms[kUnroll][kVec];
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) load2<0>(x, xdt, base + u * (kBlock * kVec), v[u][0], v[u][1]);
+    bool miss = false;
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) {
+#pragma unroll
+      for (int q = 0; q < kVec; ++q) {
+        const double j = v[u][q] - clo[u][q];
+        const bool hit = (j >= 0.0) & (j < clen[u][q]) & (__builtin_floor(v[u][q]) == v[u][q]);
+        ms[u][q] = !hit;
+        miss |= !hit;
+        r[u][q] = tab[(size_t)ccol[u][q] * stride + (hit ? (unsigned)j : 0u)];
+      }
+    }
+    if (miss) {
+#pragma unroll
+      for (int u = 0; u < kUnroll; ++u) {
+#pragma unroll
+        for (int q = 0; q < kVec; ++q) {
+          if (ms[u][q]) r[u][q] = dcol_exact<D, FN>(v[u][q], pa, ccol[u][q]);
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) store2<0>(out, odt, base + u * (kBlock * kVec), r[u][0], r[u][1]);
+  }
+  for (long long i = ntiles * kTile + (long long)blockIdx.x * kBlock + threadIdx.x; i < n; i += (long long)gridDim.x * kBlock)
+    store1(out, odt, i, dcol_exact<D, FN>(load1(x, xdt, i), pa, (unsigned)((unsigned long long)i % P)));
+}
+constexpr unsigned kDColMinStride = 64;  // a workspace that cannot hold this many values per column is not used
+inline unsigned dcol_stride(size_t ws_doubles, unsigned long long P) {  // the longest window the workspace can hold for every column
+  if (ws_doubles <= 2 * P + kDColHdr) return 0;
+  unsigned long long s = (ws_doubles - 2 * P - kDColHdr) / P;
+  s = s > (unsigned long long)kDTabMax ? (unsigned long long)kDTabMax : s;
+  return (unsigned)(s & ~7ull);
+}
+
 struct GenericOps {
   DevOperand x;
   DevOperand p[kMaxParams];
@@ -1904,6 +2024,27 @@ template <int D, int FN, bool REDUCE> int launch_fn(const LaunchArgs& a) {
     const void* xp = a.x.ptr;
     void* op = a.out;
     long long nn = n;
+    if constexpr (!REDUCE && dtab_this<DD, FN>()) {
+      // discrete families, row-periodic parameters, large n: one window of exact values per column in the workspace
+      const unsigned stride = !all_scalar ? dcol_stride(a.ews_doubles, P) : 0;
+      unsigned long long a_ = P, b_ = (unsigned long long)kTile;
+      while (b_) { const unsigned long long t_ = a_ % b_; a_ = b_; b_ = t_; }
+      const long long unit = (long long)(P / a_);
+      long long pb = tiles > 8 * 256 ? 8 * 256 : tiles;
+      pb = (pb / unit) * unit;
+      const long long R = !all_scalar ? n / (long long)P : 0;
+      if (a.ews != nullptr && stride >= kDColMinStride && pb >= 1 && n / 8 >= tab_min_n() && !binning_disabled() &&
+          (double)R * (double)kTabMinN >= 4096.0 * (double)tab_min_n() && P <= 0x7fffffffull / kDTabMax) {
+        const unsigned chunks = (stride + kBlock - 1) / kBlock;
+        if (hipMemsetAsync(a.ews, 0, kDColHdr * sizeof(double), a.stream) != hipSuccess) return (int)hipGetLastError();
+        hipLaunchKernelGGL((k_dcol_ranges<D>), dim3((unsigned)((P + kBlock - 1) / kBlock)), dim3(kBlock), 0, a.stream, pa, (unsigned)P,
+                           stride, a.ews);
+        hipLaunchKernelGGL((k_dcol_build<D, FN>), dim3((unsigned)(P * chunks)), dim3(kBlock), 0, a.stream, pa, (unsigned)P, stride, a.ews);
+        hipLaunchKernelGGL((k_dcol<D, FN>), dim3((unsigned)pb), dim3(kBlock), 0, a.stream, a.x.ptr, a.x.dtype, a.out, a.out_dtype, n,
+                           (unsigned)P, pa, a.ews);
+        return (int)hipGetLastError();
+      }
+    }
     if constexpr (!REDUCE && tab_this<DD, FN>()) {
       // row-periodic parameters, large n: per-column tables (k_coltab_build + k_coltab) in the caller's workspace; the
       // partial last row, if any, goes on below

@@ -248,7 +248,7 @@ M355_HD double flog_tab(double x) {
 // k_dtab (m355_elemwise.h): the integer window a discrete family proposes for its lookup table
 constexpr int kDTabMax = 2048;
 // window around (mean, sd) clipped to [slo, shi]; false if it does not fit
-inline bool dtab_window(double mean, double sd, double slo, double shi, double& lo, int& len) {
+M355_HD bool dtab_window(double mean, double sd, double slo, double shi, double& lo, int& len) {
   if (!(mean - mean == 0.0) || !(sd - sd == 0.0)) return false;
   double a = floor(mean - 9.0 * sd - 12.0), b = ceil(mean + 14.0 * sd + 40.0);
   a = a < slo ? slo : a;

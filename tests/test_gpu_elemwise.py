@@ -621,6 +621,69 @@ def test_discrete_lookup_kernel(gpu, name, params):
         assert np.array_equal(tab, exact, equal_nan=True), (name, fn, q[~((tab == exact) | (np.isnan(tab) & np.isnan(exact)))][:5])
 
 
+@pytest.mark.parametrize("name", ["poisson", "binomial", "negativebinomial", "betabinomial", "hypergeometric", "zi_poisson",
+                                  "zi_binomial", "zi_negativebinomial"])
+def test_discrete_lookup_per_column(gpu, name):
+    """k_dcol_build + k_dcol (row-periodic parameters: one window of exact values per column in the call's workspace,
+    m355_elemwise.h), forced onto a small input: bit-identical to the exact kernels, for float64 and int64 observations,
+    counts inside and outside the windows, non-integers, NaN, infinities, and columns whose window does not fit or whose
+    parameters are out of domain (left to the exact bodies)."""
+    from distributions_amd import _lib
+
+    L = _lib.lib()
+    rng = np.random.default_rng(43)
+    m = mod(name)
+    P, R = 48, 700
+    pp = {
+        "poisson": (np.concatenate([rng.uniform(0.2, 300.0, P - 2), [1e7, -1.0]]),),
+        "binomial": (np.concatenate([rng.integers(1, 2000, P - 1), [5_000_000]]).astype(np.float64), rng.uniform(0.02, 0.98, P)),
+        "negativebinomial": (rng.uniform(0.5, 40.0, P), rng.uniform(0.05, 0.9, P)),
+        "betabinomial": (rng.integers(1, 300, P).astype(np.float64), rng.uniform(0.5, 30.0, P), rng.uniform(0.5, 30.0, P)),
+        "hypergeometric": (np.full(P, 500.0), rng.integers(1, 400, P).astype(np.float64), rng.integers(1, 300, P).astype(np.float64)),
+        "zi_poisson": (rng.uniform(0.1, 0.9, P), rng.uniform(0.5, 200.0, P)),
+        "zi_binomial": (rng.uniform(0.1, 0.9, P), rng.integers(1, 500, P).astype(np.float64), rng.uniform(0.05, 0.95, P)),
+        "zi_negativebinomial": (rng.uniform(0.1, 0.9, P), rng.uniform(0.5, 30.0, P), rng.uniform(0.05, 0.9, P)),
+    }[name]
+    with np.errstate(all="ignore"):
+        k = np.asarray(m.rvs(*[np.where(np.isfinite(a) & (a > 0), a, 1.0) if j == 0 and name == "poisson" else a for j, a in enumerate(pp)],
+                             size=(R, P), random_state=9), dtype=np.float64)
+    k[0, :12] = [np.nan, np.inf, -np.inf, -1.0, 0.0, 0.5, 1e18, 3.0, 2.5, 1e6, -0.0, 1.0]
+    k[1] = k[2] * 3 + 50  # far in the upper tails: outside most windows
+    for obs in (k, np.where(np.isfinite(k), np.clip(k, -1e15, 1e15), 0).astype(np.int64)):
+        for fn in ("cdf", "sf", "logcdf", "logsf"):
+            old = L.m355_set_tab_min_n(2**62)
+            try:
+                with np.errstate(all="ignore"):
+                    exact = getattr(m, fn)(obs, *pp)
+                L.m355_set_tab_min_n(1)
+                with np.errstate(all="ignore"):
+                    tab = getattr(m, fn)(obs, *pp)
+            finally:
+                L.m355_set_tab_min_n(old)
+            assert tab.shape == (R, P)
+            assert np.array_equal(tab, exact, equal_nan=True), (name, fn, np.argwhere(~((tab == exact) | (np.isnan(tab) & np.isnan(exact))))[:5])
+    # the kernels really ran: after a call through the C-ABI with a NaN-filled workspace the column headers are in it
+    import torch
+
+    from distributions_amd import raw
+
+    ws = torch.full((8 + P * (2 + 2048),), float("nan"), dtype=torch.float64, device=gpu)
+    xd = torch.from_numpy(k).to(gpu)
+    out = torch.empty_like(xd)
+    old = L.m355_set_tab_min_n(1)
+    try:
+        raw.elemwise_into(name, "logcdf", xd, tuple(torch.from_numpy(np.ascontiguousarray(a)).to(gpu) for a in pp), out,
+                          workspace=ws.view(torch.uint8))
+        torch.cuda.synchronize()
+    finally:
+        L.m355_set_tab_min_n(old)
+    hdr = ws[8 : 8 + 2 * P].cpu().numpy().reshape(P, 2)
+    assert int(ws[:1].view(torch.int32)[0].item()) == int(hdr[:, 1].max())  # the tables' stride: the longest window
+    assert not np.isnan(hdr).any() and (hdr[:, 1] > 0).sum() >= P // 2, hdr[:4]
+    if name == "poisson":
+        assert hdr[-1, 1] == -1.0 and hdr[-2, 1] == -1.0  # mu = -1 and mu = 1e7 (a window of > 2048 values): no table
+
+
 @pytest.mark.parametrize("h, z", H.POLYAGAMMA_CASES)
 def test_polyagamma(gpu, h, z):
     """polyagamma: no SciPy counterpart -- every function against the oracle (series density,
