@@ -240,14 +240,25 @@ M355_DEV PtrsK ptrs_setup(double mu) {
   c.vr = 0.9277 - 3.6224 / (c.b - 2.0);
   return c;
 }
-// One PTRS attempt from the uniform pair (u1, v): true = accepted, k holds the draw.
-M355_DEV bool ptrs_attempt(const PtrsK& c, double u1, double v, double& k) {
+// One PTRS attempt from the uniform pair (u1, v), in two parts: the squeeze tests (1 = accepted, 0 = rejected, 2 = the
+// logarithmic test has to decide; k holds the candidate, us the distance of u from the ends) and that test.  The
+// compacting kernel queues the undecided attempts of a wavefront and runs the logarithms on 64 of them at a time.
+M355_DEV int ptrs_fast(const PtrsK& c, double u1, double v, double& k, double& us) {
   const double u = u1 - 0.5;
-  const double us = 0.5 - __builtin_fabs(u);
+  us = 0.5 - __builtin_fabs(u);
   k = floor_((2.0 * c.a / us + c.b) * u + c.mu + 0.43);
-  if (us >= 0.07 && v <= c.vr) return true;
-  if (k < 0.0 || (us < 0.013 && v > us)) return false;
+  if (us >= 0.07 && v <= c.vr) return 1;
+  if (k < 0.0 || (us < 0.013 && v > us)) return 0;
+  return 2;
+}
+M355_DEV bool ptrs_slow(const PtrsK& c, double k, double us, double v) {
   return flog_tab(v) + c.log_invalpha - flog_tab(c.a / (us * us) + c.b) <= -c.mu + k * c.loglam - lfactorial(k);
+}
+// true = accepted, k holds the draw.
+M355_DEV bool ptrs_attempt(const PtrsK& c, double u1, double v, double& k) {
+  double us;
+  const int f = ptrs_fast(c, u1, v, k, us);
+  return f == 2 ? ptrs_slow(c, k, us, v) : f == 1;
 }
 
 // Poisson(mu) as a double holding an integer.  mu == 0 -> 0; mu < 0 or NaN -> NaN.
@@ -312,16 +323,24 @@ M355_DEV BtrsK btrs_setup(double n, double p) {
   k.hm = (k.m + 0.5) * flog_tab((k.m + 1.0) / (k.r * (n - k.m + 1.0))) + stirling_tail(k.m) + stirling_tail(n - k.m);
   return k;
 }
-M355_DEV bool btrs_attempt(const BtrsK& c, double u1, double v, double& k) {
+M355_DEV int btrs_fast(const BtrsK& c, double u1, double v, double& k, double& us) {  // (as ptrs_fast)
   const double u = u1 - 0.5;
-  const double us = 0.5 - __builtin_fabs(u);
+  us = 0.5 - __builtin_fabs(u);
   k = floor_((2.0 * c.a / us + c.b) * u + c.c);
-  if (us >= 0.07 && v <= c.vr) return true;
-  if (k < 0.0 || k > c.n) return false;
+  if (us >= 0.07 && v <= c.vr) return 1;
+  if (k < 0.0 || k > c.n) return 0;
+  return 2;
+}
+M355_DEV bool btrs_slow(const BtrsK& c, double k, double us, double v) {
   const double lv = flog_tab(v * c.alpha / (c.a / (us * us) + c.b));
   const double upper = c.hm + (c.n + 1.0) * flog_tab((c.n - c.m + 1.0) / (c.n - k + 1.0)) +
                        (k + 0.5) * flog_tab(c.r * (c.n - k + 1.0) / (k + 1.0)) - stirling_tail(k) - stirling_tail(c.n - k);
   return lv <= upper;
+}
+M355_DEV bool btrs_attempt(const BtrsK& c, double u1, double v, double& k) {
+  double us;
+  const int f = btrs_fast(c, u1, v, k, us);
+  return f == 2 ? btrs_slow(c, k, us, v) : f == 1;
 }
 
 // Binomial(n, p) as a double holding an integer.  n must be a non-negative integer value.

@@ -53,12 +53,24 @@ __global__ __launch_bounds__(kBlock) void k_rvs_normal_pairs(double* __restrict_
 // so all 64 lanes keep proposing instead of idling until the slowest lane of a fixed group of 64
 // elements is accepted.  A draw still depends only on (seed, stream, element index, attempt
 // number), never on the lane that computed it: the output is identical to k_rvs.
+// Round 3: the squeeze tests decide ~86 % of the attempts; the rest need three logarithms, and with one such lane in a
+// wavefront all 64 paid for them every round.  An undecided attempt now goes to the wavefront's queue in LDS
+// (element, attempt number, candidate, us, v) and frees its lane; when 64 have gathered, the logarithmic test runs
+// once for all of them, each lane on one queued attempt.  An element whose queued attempt fails goes to a second list
+// (element, next attempt number), from which the refill step serves free lanes before it hands out new elements.
+constexpr int kQueueCap = 128;  // at most 63 waiting + 64 pushed in one round
 template <int D>
 __global__ __launch_bounds__(kBlock) void k_rvs_compact(void* __restrict__ out, int odt, long long n, double p0, double p1,
                                                         unsigned long long seed, unsigned stream,
                                                         unsigned long long offset) {
+  __shared__ long long q_idx[kBlock / 64][kQueueCap];
+  __shared__ unsigned q_att[kBlock / 64][kQueueCap];
+  __shared__ double q_k[kBlock / 64][kQueueCap], q_us[kBlock / 64][kQueueCap], q_v[kBlock / 64][kQueueCap];
+  __shared__ long long r_idx[kBlock / 64][kQueueCap];  // elements to retry (at most 64 waiting + 64 from one test batch)
+  __shared__ unsigned r_att[kBlock / 64][kQueueCap];
   log_table_init();
-  const long long wave = (long long)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const long long wave = (long long)blockIdx.x * (kBlock / 64) + wv;
   const long long nwaves = (long long)gridDim.x * (kBlock / 64);
   const long long chunk = ((n + nwaves - 1) / nwaves + 63) & ~63ll;
   const long long w1 = (wave + 1) * chunk < n ? (wave + 1) * chunk : n;
@@ -68,40 +80,124 @@ __global__ __launch_bounds__(kBlock) void k_rvs_compact(void* __restrict__ out, 
   BtrsK bk;
   if constexpr (D == M355_POISSON) pk = ptrs_setup(p0);
   else bk = btrs_setup(p0, p1);
+  auto block = [&](long long idx, unsigned attempt, double& u1, double& v) {
+    const unsigned long long c = offset + (unsigned long long)idx;
+    const Philox ph = philox4x32_10((unsigned)c, (unsigned)(c >> 32), attempt, stream, (unsigned)seed, (unsigned)(seed >> 32));
+    u1 = u53(ph.c[0], ph.c[1]);
+    v = u53(ph.c[2], ph.c[3]);
+  };
+  auto finish = [&](long long idx, double k) {
+    if constexpr (D == M355_BINOMIAL) {
+      if (bk.flip) k = bk.n - k;
+    }
+    store_draw(out, odt, idx, k);
+  };
+  int retry = 0;  // wave-uniform: entries of the retry list
+  // the logarithmic test for `cnt` queued attempts (entries [first, first + cnt) of the queue), one per lane
+  auto drain = [&](int first, int cnt) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    bool again = false;
+    long long qi = -1;
+    unsigned qa = 0;
+    if (lane < cnt) {
+      qi = q_idx[wv][first + lane];
+      qa = q_att[wv][first + lane];
+      const double k = q_k[wv][first + lane];
+      bool ok;
+      if constexpr (D == M355_POISSON) ok = ptrs_slow(pk, k, q_us[wv][first + lane], q_v[wv][first + lane]);
+      else ok = btrs_slow(bk, k, q_us[wv][first + lane], q_v[wv][first + lane]);
+      if (ok || qa >= (unsigned)kMaxAttempts) finish(qi, k);  // (qa: the number of the NEXT attempt)
+      else again = true;
+    }
+    const unsigned long long am = __ballot(again);
+    if (again) {
+      const int at = retry + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(am >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)am, 0u));
+      r_idx[wv][at] = qi;
+      r_att[wv][at] = qa;
+    }
+    retry += __popcll(am);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  };
   long long idx = -1;  // element held by this lane (-1: none)
   unsigned attempt = 0;
+  int queued = 0;  // wave-uniform
   for (;;) {
-    // refill the free lanes from the chunk
+    // refill the free lanes: first from the retry list, then from the chunk
     const bool freed = idx < 0;
     const unsigned long long fm = __ballot(freed);
-    const unsigned below = __builtin_amdgcn_mbcnt_hi((unsigned)(fm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)fm, 0u));
+    const int below = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(fm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)fm, 0u));
+    const int nfree = __popcll(fm);
+    const int from_retry = nfree < retry ? nfree : retry;
     if (freed) {
-      const long long cand = next + below;
-      if (cand < w1) {
-        idx = cand;
-        attempt = 0;
+      if (below < from_retry) {
+        idx = r_idx[wv][retry - 1 - below];
+        attempt = r_att[wv][retry - 1 - below];
+      } else {
+        const long long cand = next + (below - from_retry);
+        if (cand < w1) {
+          idx = cand;
+          attempt = 0;
+        }
       }
     }
-    next += __popcll(fm);
+    retry -= from_retry;
+    next += nfree - from_retry;
     if (next > w1) next = w1;
     const bool active = idx >= 0;
-    if (__ballot(active) == 0ull) break;  // chunk exhausted and every lane has stored its draw
-    if (active) {
-      const unsigned long long c = offset + (unsigned long long)idx;
-      const Philox ph = philox4x32_10((unsigned)c, (unsigned)(c >> 32), attempt, stream, (unsigned)seed, (unsigned)(seed >> 32));
-      attempt += 1;
-      const double u1 = u53(ph.c[0], ph.c[1]), v = u53(ph.c[2], ph.c[3]);
-      double k;
-      bool ok;
-      if constexpr (D == M355_POISSON) {
-        ok = ptrs_attempt(pk, u1, v, k);
-      } else {
-        ok = btrs_attempt(bk, u1, v, k);
-        if (bk.flip) k = bk.n - k;
+    if (__ballot(active) == 0ull) {
+      // nothing held and nothing new: test what is queued; failures come back through the retry list
+      // (no lane holds anything, so the retry list is empty: at most 127 queued, 64 at a time)
+      if (queued > 64) {
+        queued -= 64;
+        drain(queued, 64);
+        continue;
       }
-      if (ok || attempt >= (unsigned)kMaxAttempts) {
-        store_draw(out, odt, idx, k);
+      if (queued > 0) {
+        drain(0, queued);
+        queued = 0;
+      }
+      if (retry == 0) break;
+      continue;
+    }
+    bool slow = false;
+    double k = 0.0, us = 0.0, v = 0.0;
+    const bool can_queue = queued + 64 <= kQueueCap;  // wave-uniform: room for one more round of undecided attempts
+    if (active) {
+      double u1;
+      block(idx, attempt, u1, v);
+      attempt += 1;
+      int f;
+      if constexpr (D == M355_POISSON) f = ptrs_fast(pk, u1, v, k, us);
+      else f = btrs_fast(bk, u1, v, k, us);
+      if (f == 2 && !can_queue) {  // (both lists full: practically never; decide here, as the per-lane loop does)
+        bool ok;
+        if constexpr (D == M355_POISSON) ok = ptrs_slow(pk, k, us, v);
+        else ok = btrs_slow(bk, k, us, v);
+        f = ok ? 1 : 0;
+      }
+      if (f == 1 || (f == 0 && attempt >= (unsigned)kMaxAttempts)) {
+        finish(idx, k);
         idx = -1;
+      }
+      slow = f == 2;
+    }
+    const unsigned long long sm = __ballot(slow);
+    if (sm != 0ull) {
+      if (slow) {
+        const int at = queued + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(sm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)sm, 0u));
+        q_idx[wv][at] = idx;
+        q_att[wv][at] = attempt;
+        q_k[wv][at] = k;
+        q_us[wv][at] = us;
+        q_v[wv][at] = v;
+        idx = -1;
+      }
+      queued += __popcll(sm);
+      if (queued >= 64 && retry + 64 <= kQueueCap) {
+        queued -= 64;
+        drain(queued, 64);
       }
     }
   }
