@@ -598,6 +598,13 @@ template <> struct Dist<M355_LOGITNORMAL> {
 template <> struct Dist<M355_INVERSEGAMMA> {
   static constexpr int kMinWaves = 3;  // binned kernel: 168-VGPR budget around the inlined gammaincinv_p (m355_elemwise.h)
   static constexpr int kBinned = 1;
+  // quantile tables: the reference takes gammaincinv at 1 - q (inversegamma.py:60-61, scaledinversechisquared.py:56-59),
+  // which rounds for small q -- a staircase in q, 3e-10 of x at q = 1e-8 -- but is the smooth TRUE quantile of
+  // q' = 1 - fl(1 - q).  So the lookup forms its logit from (1 - den, den) with the reference's own den (tab_q_den),
+  // and the nodes below the median are true quantiles: one Newton step on logcdf (kTabPolishLower, m355_elemwise.h;
+  // evaluated through 1 - p they carried that same rounding as noise and their cells failed validation)
+  static constexpr bool kTabPolishLower = true;
+  static M355_DEV double tab_q_den(double q) { return 1.0 - q; }
   static constexpr int NP = 2;
   struct K { double alpha, beta, lga, c; };
   static M355_HD K derive(const double* p) {
@@ -730,6 +737,13 @@ template <> struct Dist<M355_CHISQUARED> {
 template <> struct Dist<M355_SCALEDINVERSECHISQUARED> {
   static constexpr int kMinWaves = 3;  // binned kernel: 168-VGPR budget around the inlined gammaincinv_p (m355_elemwise.h)
   static constexpr int kBinned = 1;
+  // quantile tables: the reference takes gammaincinv at 1 - q (inversegamma.py:60-61, scaledinversechisquared.py:56-59),
+  // which rounds for small q -- a staircase in q, 3e-10 of x at q = 1e-8 -- but is the smooth TRUE quantile of
+  // q' = 1 - fl(1 - q).  So the lookup forms its logit from (1 - den, den) with the reference's own den (tab_q_den),
+  // and the nodes below the median are true quantiles: one Newton step on logcdf (kTabPolishLower, m355_elemwise.h;
+  // evaluated through 1 - p they carried that same rounding as noise and their cells failed validation)
+  static constexpr bool kTabPolishLower = true;
+  static M355_DEV double tab_q_den(double q) { return 1.0 - q; }
   static constexpr int NP = 2;
   struct K { double nu, tau2, h, ht, lgh, c; };  // h = nu/2, ht = h*tau2
   static M355_HD K derive(const double* p) {
@@ -897,6 +911,11 @@ template <> struct Dist<M355_BETASCALED> {
   // k_tab: logit of the position in (lower, upper), both differences formed from x directly (conditions as for beta)
   static M355_HD bool tab_ok(const K& k) { return k.a >= 1.0 && k.b >= 1.0 && k.a + k.b <= 500.0 && k.w > 0.0 && k.w < kInf; }
   static M355_HD double tab_tol(const K& k) { return 1e-14 * (k.a + k.b > 40.0 ? (k.a + k.b) * (1.0 / 40.0) : 1.0); }  // (as Dist<M355_BETA>)
+  // quantile cells: the root lower + p (upper - lower) is rounded on the scale of the larger end (m355_elemwise.h, tab_qfloor)
+  static M355_DEV double tab_qfloor(const K& k) {
+    const double al = __builtin_fabs(k.lo), ah = __builtin_fabs(k.hi);
+    return al > ah ? al : ah;
+  }
   // betascaled.py:71-72 cdf = exp(logcdf); betascaled.py:88-89 sf = 1 - cdf
   template <int FN> static constexpr TabRoute tab_route() {
     return FN == M355_CDF ? TabRoute{M355_LOGCDF, kTabEpiExp} : TabRoute{M355_LOGCDF, kTabEpiOneMinusExp};
