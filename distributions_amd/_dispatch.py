@@ -175,7 +175,7 @@ def _table_workspace(dist: str, fn: str, pl: Plan, torch, device):
             return None  # not row-periodic: the library's generic kernel
         period = int(op.mod)
     densities = fn in ("logpdf", "pdf")
-    if period and dist in DTABLE_DISTS and fn in ("cdf", "sf", "logcdf", "logsf") and pl.n >= 8 * int(_lib.lib().m355_tab_min_n()):
+    if period and dist in DTABLE_DISTS and fn in ("cdf", "sf", "logcdf", "logsf", "ppf", "isf") and pl.n >= 8 * int(_lib.lib().m355_tab_min_n()):
         need = int(_lib.lib().m355_elemwise_workspace_bytes_for(pl.n, period))
         return torch.empty(need, dtype=torch.uint8, device=device) if 0 < need <= _TABLE_WS_MAX else None
     if period == 0 and (densities or dist not in TABLE_DISTS):

@@ -150,8 +150,8 @@ size_t m355_elemwise_workspace_bytes_for(int64_t n, int64_t period) {
   // the derived constants of the P parameter sets (k_periodic_fixed: stored logpdf / pdf), and, for periods the table
   // kernels take, the per-column tables and miss words of logcdf / logsf / cdf / sf / ppf / isf
   size_t need = (size_t)period * 16 * sizeof(double);
-  {  // the discrete families' windows (k_dcol): two header doubles and up to kDTabMax values per column
-    const size_t t = ((size_t)period * (2 + (size_t)m355::kDTabMax) + m355::kDColHdr) * sizeof(double);
+  {  // the discrete families' windows (k_dcol): two header doubles and up to 2 x kDTabMax values per column
+    const size_t t = ((size_t)period * (2 + 2 * (size_t)m355::kDTabMax) + m355::kDColHdr) * sizeof(double);  // (quantiles: cdf and pmf)
     need = t > need ? t : need;
   }
   if (period % m355::kCtCols == 0) {

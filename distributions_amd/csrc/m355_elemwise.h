@@ -1798,10 +1798,145 @@ __global__ __launch_bounds__(kBlock) void k_dcol(const void* __restrict__ x, int
   for (long long i = ntiles * kTile + (long long)blockIdx.x * kBlock + threadIdx.x; i < n; i += (long long)gridDim.x * kBlock)
     store1(out, odt, i, dcol_exact<D, FN>(load1(x, xdt, i), pa, (unsigned)((unsigned long long)i % P)));
 }
+// Column groups with the windows in LDS (P a multiple of 16): k_dcol's gathers miss the L1 -- a workgroup there meets all P
+// columns -- so every element pulled a 128-byte line from L2.  k_dcolg gives a workgroup of 1024 threads 16 adjacent
+// columns (a row's 16 values are one 128-byte line) and a slice of the rows, copies the 16 windows to LDS when the
+// call's longest window fits kDcgS entries (otherwise it reads them from the workspace as k_dcol does) and looks up
+// there.  Quantiles (PPF / ISF): find_ppf_discrete itself on two windows per column (cdf and pmf), as k_dtab_ppf does
+// with scalar parameters -- the same iterates, bit for bit.
+constexpr int kDcgCols = 16, kDcgThreads = 1024, kDcgS = 512, kDcgRowsPerTrip = 4;
+template <int FN> constexpr size_t dcolg_lds_bytes() {
+  return (size_t)kDcgCols * kDcgS * sizeof(double) * ((FN == M355_PPF || FN == M355_ISF) ? 2 : 1);
+}
+template <int D>
+__global__ __launch_bounds__(kBlock) void k_dcol_build_q(PeriodicParams pa, unsigned P, unsigned max_stride, double* __restrict__ ws) {
+  using DD = Dist<D>;
+  const unsigned chunks = (max_stride + kBlock - 1) / kBlock;
+  const unsigned p = blockIdx.x / chunks, ch = blockIdx.x % chunks;
+  const int len = (int)ws[kDColHdr + 2 * (size_t)p + 1];
+  if ((int)(ch * kBlock) >= len) return;  // (workgroup-uniform)
+  if constexpr (uses_log_table<DD>::value) log_table_init();
+  const unsigned stride = (unsigned)*reinterpret_cast<const int*>(ws);
+  const double lo = ws[kDColHdr + 2 * (size_t)p];
+  double pp[kMaxParams];
+#pragma unroll
+  for (int q = 0; q < kMaxParams; ++q) pp[q] = (q < DD::NP && pa.ptr[q]) ? pa.ptr[q][p] : pa.scalar[q];
+  const typename DD::K k = DD::derive(pp);
+  const int j = (int)(ch * kBlock + threadIdx.x);
+  if (j < len) {
+    double* tab = ws + kDColHdr + 2 * (size_t)P;
+    tab[(size_t)p * stride + j] = DD::dtab_cdf(lo + (double)j, k);
+    tab[(size_t)P * stride + (size_t)p * stride + j] = DD::dtab_pmf(lo + (double)j, k);
+  }
+}
+template <int D, int FN>
+__global__ __launch_bounds__(kDcgThreads) void k_dcolg(const void* __restrict__ x, int xdt, void* __restrict__ out, int odt, long long R,
+                                                       unsigned P, unsigned rows_per_wg, PeriodicParams pa,
+                                                       const double* __restrict__ ws) {
+  using DD = Dist<D>;
+  constexpr bool Q = FN == M355_PPF || FN == M355_ISF;
+  extern __shared__ __attribute__((aligned(16))) double dcg_lds[];
+  if constexpr (uses_log_table<DD>::value) log_table_init();
+  const unsigned stride = (unsigned)*reinterpret_cast<const int*>(ws);
+  const double* hdr = ws + kDColHdr;
+  const double* tab = hdr + 2 * (size_t)P;
+  const double* tabp = tab + (size_t)P * stride;  // (quantiles: the pmf windows)
+  const bool in_lds = stride <= (unsigned)kDcgS;  // workgroup-uniform
+  const unsigned G = P / kDcgCols, g = blockIdx.x % G, chunk = blockIdx.x / G;
+  const unsigned col0 = g * kDcgCols, c = threadIdx.x & (kDcgCols - 1), rl = threadIdx.x >> 4;
+  if (in_lds) {
+    for (unsigned e = threadIdx.x; e < kDcgCols * stride; e += kDcgThreads) {
+      const unsigned cc = e / stride, j = e - cc * stride;
+      dcg_lds[cc * kDcgS + j] = tab[(size_t)(col0 + cc) * stride + j];
+      if constexpr (Q) dcg_lds[(kDcgCols + cc) * kDcgS + j] = tabp[(size_t)(col0 + cc) * stride + j];
+    }
+  }
+  __syncthreads();
+  const unsigned col = col0 + c;
+  const double lo = hdr[2 * (size_t)col], flen = hdr[2 * (size_t)col + 1];
+  const long long r0 = (long long)chunk * rows_per_wg;
+  const long long r1 = r0 + rows_per_wg < R ? r0 + rows_per_wg : R;
+  constexpr int kRowLanes = kDcgThreads / kDcgCols;  // 64
+  auto rows = [&](auto cdf_at, auto pmf_at) {  // cdf_at(j) / pmf_at(j): the windows of this thread's column
+    if constexpr (!Q) {
+      for (long long r = r0 + rl; r < r1; r += kRowLanes * kDcgRowsPerTrip) {
+        double v[kDcgRowsPerTrip], res[kDcgRowsPerTrip];
+        bool ms[kDcgRowsPerTrip];
+#pragma unroll
+        for (int u = 0; u < kDcgRowsPerTrip; ++u) {
+          const long long rr = r + u * kRowLanes;
+          v[u] = rr < r1 ? load1(x, xdt, rr * (long long)P + col) : lo;
+        }
+        bool miss = false;
+#pragma unroll
+        for (int u = 0; u < kDcgRowsPerTrip; ++u) {
+          const double j = v[u] - lo;
+          const bool hit = (j >= 0.0) & (j < flen) & (__builtin_floor(v[u]) == v[u]);
+          ms[u] = !hit & (r + u * kRowLanes < r1);
+          miss |= ms[u];
+          res[u] = cdf_at(hit ? (unsigned)j : 0u);
+        }
+        if (miss) {
+#pragma unroll
+          for (int u = 0; u < kDcgRowsPerTrip; ++u) {
+            if (ms[u]) res[u] = dcol_exact<D, FN>(v[u], pa, col);
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < kDcgRowsPerTrip; ++u) {
+          const long long rr = r + u * kRowLanes;
+          if (rr < r1) store1(out, odt, rr * (long long)P + col, res[u]);
+        }
+      }
+    } else {
+      double pp[kMaxParams];
+#pragma unroll
+      for (int q = 0; q < kMaxParams; ++q) pp[q] = (q < DD::NP && pa.ptr[q]) ? pa.ptr[q][col] : pa.scalar[q];
+      const typename DD::K k = DD::derive(pp);
+      auto cdf = [&](double v) -> double {
+        const double j = v - lo;
+        if ((j >= 0.0) & (j < flen) & (__builtin_floor(v) == v)) return cdf_at((unsigned)j);
+        return dtab_cdf_exact<D>(v, k);
+      };
+      auto pmf = [&](double v) -> double {
+        const double j = v - lo;
+        if ((j >= 0.0) & (j < flen) & (__builtin_floor(v) == v)) return pmf_at((unsigned)j);
+        return dtab_pmf_exact<D>(v, k);
+      };
+      for (long long r = r0 + rl; r < r1; r += kRowLanes) {
+        const double xv = load1(x, xdt, r * (long long)P + col);
+        const double q = (FN == M355_ISF) ? 1.0 - xv : xv;
+        store1(out, odt, r * (long long)P + col, DD::ppf_with(q, k, cdf, pmf));
+      }
+    }
+  };
+  if (in_lds) {
+    const double* tc = dcg_lds + c * kDcgS;
+    const double* tp = dcg_lds + (kDcgCols + c) * kDcgS;
+    rows([&](unsigned j) { return tc[j]; }, [&](unsigned j) { return tp[j]; });
+  } else {
+    const double* tc = tab + (size_t)col * stride;
+    const double* tp = tabp + (size_t)col * stride;
+    rows([&](unsigned j) { return tc[j]; }, [&](unsigned j) { return tp[j]; });
+  }
+}
+template <int D, int FN> bool dcolg_ready() {  // (as coltab_ready: the LDS attribute once per device)
+  static std::atomic<unsigned char> state[kMaxDevicesTracked];
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevicesTracked) return false;
+  unsigned char st = state[dev].load(std::memory_order_acquire);
+  if (st == 0) {
+    st = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dcolg<D, FN>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                             (int)dcolg_lds_bytes<FN>()) == hipSuccess ? 1 : 2;
+    if (st == 2) (void)hipGetLastError();
+    state[dev].store(st, std::memory_order_release);
+  }
+  return st == 1;
+}
 constexpr unsigned kDColMinStride = 64;  // a workspace that cannot hold this many values per column is not used
-inline unsigned dcol_stride(size_t ws_doubles, unsigned long long P) {  // the longest window the workspace can hold for every column
+inline unsigned dcol_stride(size_t ws_doubles, unsigned long long P, int tables = 1) {  // the longest window the workspace can hold for every column
   if (ws_doubles <= 2 * P + kDColHdr) return 0;
-  unsigned long long s = (ws_doubles - 2 * P - kDColHdr) / P;
+  unsigned long long s = (ws_doubles - 2 * P - kDColHdr) / (P * (unsigned long long)tables);
   s = s > (unsigned long long)kDTabMax ? (unsigned long long)kDTabMax : s;
   return (unsigned)(s & ~7ull);
 }
@@ -2053,24 +2188,42 @@ template <int D, int FN, bool REDUCE> int launch_fn(const LaunchArgs& a) {
     const void* xp = a.x.ptr;
     void* op = a.out;
     long long nn = n;
-    if constexpr (!REDUCE && dtab_this<DD, FN>()) {
+    if constexpr (!REDUCE && has_dtab<DD>::value && FN >= M355_LOGCDF && FN != M355_PDF) {
       // discrete families, row-periodic parameters, large n: one window of exact values per column in the workspace
-      const unsigned stride = !all_scalar ? dcol_stride(a.ews_doubles, P) : 0;
+      // (quantiles: two, cdf and pmf); column groups with the windows in LDS when P is a multiple of 16 (k_dcolg)
+      constexpr bool Q = FN == M355_PPF || FN == M355_ISF;
+      const unsigned stride = !all_scalar ? dcol_stride(a.ews_doubles, P, Q ? 2 : 1) : 0;
       unsigned long long a_ = P, b_ = (unsigned long long)kTile;
       while (b_) { const unsigned long long t_ = a_ % b_; a_ = b_; b_ = t_; }
       const long long unit = (long long)(P / a_);
       long long pb = tiles > 8 * 256 ? 8 * 256 : tiles;
       pb = (pb / unit) * unit;
       const long long R = !all_scalar ? n / (long long)P : 0;
-      if (a.ews != nullptr && stride >= kDColMinStride && pb >= 1 && n / 8 >= tab_min_n() && !binning_disabled() &&
-          (double)R * (double)kTabMinN >= 4096.0 * (double)tab_min_n() && P <= 0x7fffffffull / kDTabMax) {
+      const bool groups = P % kDcgCols == 0 && R * (long long)P == n;
+      if (a.ews != nullptr && stride >= kDColMinStride && n / 8 >= tab_min_n() && !binning_disabled() &&
+          (double)R * (double)kTabMinN >= 4096.0 * (double)tab_min_n() && P <= 0x7fffffffull / (2 * kDTabMax) &&
+          (groups ? dcolg_ready<D, FN>() : (!Q && pb >= 1))) {
         const unsigned chunks = (stride + kBlock - 1) / kBlock;
         if (hipMemsetAsync(a.ews, 0, kDColHdr * sizeof(double), a.stream) != hipSuccess) return (int)hipGetLastError();
         hipLaunchKernelGGL((k_dcol_ranges<D>), dim3((unsigned)((P + kBlock - 1) / kBlock)), dim3(kBlock), 0, a.stream, pa, (unsigned)P,
                            stride, a.ews);
-        hipLaunchKernelGGL((k_dcol_build<D, FN>), dim3((unsigned)(P * chunks)), dim3(kBlock), 0, a.stream, pa, (unsigned)P, stride, a.ews);
-        hipLaunchKernelGGL((k_dcol<D, FN>), dim3((unsigned)pb), dim3(kBlock), 0, a.stream, a.x.ptr, a.x.dtype, a.out, a.out_dtype, n,
-                           (unsigned)P, pa, a.ews);
+        if constexpr (Q)
+          hipLaunchKernelGGL((k_dcol_build_q<D>), dim3((unsigned)(P * chunks)), dim3(kBlock), 0, a.stream, pa, (unsigned)P, stride, a.ews);
+        else
+          hipLaunchKernelGGL((k_dcol_build<D, FN>), dim3((unsigned)(P * chunks)), dim3(kBlock), 0, a.stream, pa, (unsigned)P, stride, a.ews);
+        if (groups) {
+          const unsigned G = (unsigned)(P / kDcgCols);
+          unsigned C = 1024 / G;  // ~4 workgroups per CU in the queue
+          C = C < 1 ? 1 : C;
+          long long rows_per_wg = (R + C - 1) / C;
+          rows_per_wg = ((rows_per_wg + 255) / 256) * 256;
+          C = (unsigned)((R + rows_per_wg - 1) / rows_per_wg);
+          hipLaunchKernelGGL((k_dcolg<D, FN>), dim3(G * C), dim3(kDcgThreads), dcolg_lds_bytes<FN>(), a.stream, a.x.ptr, a.x.dtype, a.out,
+                             a.out_dtype, R, (unsigned)P, (unsigned)rows_per_wg, pa, a.ews);
+        } else if constexpr (!Q) {
+          hipLaunchKernelGGL((k_dcol<D, FN>), dim3((unsigned)pb), dim3(kBlock), 0, a.stream, a.x.ptr, a.x.dtype, a.out, a.out_dtype, n,
+                             (unsigned)P, pa, a.ews);
+        }
         return (int)hipGetLastError();
       }
     }

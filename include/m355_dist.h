@@ -166,8 +166,8 @@ int m355_elemwise_ws(int dist, int fn, int out_dtype, int64_t n, const m355_oper
  * Tuning knob of m355_elemwise_ws, no counterpart in the reference: the element count from which the launch-time tables
  * are used -- scalar parameters: n >= min_n; row-periodic parameters: n >= 8 * min_n (and >= 8192 rows at the default);
  * also the threshold of the discrete families' lookup kernels (k_dtab: exact values over a window of integers,
- * bit-identical results, no workspace; with row-periodic parameters k_dcol: one window per column in the workspace,
- * 8 * (2 + 2048) bytes per column, from 8 * min_n elements and 4096 rows).  Returns the previous threshold; min_n < 0 restores the default (2^21),
+ * bit-identical results, no workspace; with row-periodic parameters k_dcolg / k_dcol: one window per column in the
+ * workspace, quantiles included, 8 * (2 + 2 * 2048) bytes per column, from 8 * min_n elements and 4096 rows).  Returns the previous threshold; min_n < 0 restores the default (2^21),
  * INT64_MAX switches the tables off.  Process-wide (an atomic: safe beside launches on other threads, which see the old
  * or the new value).
  *

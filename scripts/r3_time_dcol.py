@@ -27,20 +27,23 @@ for name, pp in cases.items():
     m = importlib.import_module(f"distributions_amd.{name}")
     x = m.rvs(*[p.reshape(1, P) for p in pd], size=(R, P), random_state=5).reshape(-1).contiguous()
     out = torch.empty(R * P, dtype=torch.float64, device=dev)
-    for fn in ("logcdf", "cdf"):
+    qd = torch.rand(R * P, dtype=torch.float64, device=dev)
+    for fn in ("logcdf", "cdf", "ppf"):
         res = {}
         for label, thr in (("exact", 2**62), ("k_dcol", -1)):
             old = L.m355_set_tab_min_n(thr)
             try:
-                for _ in range(2):
-                    raw.elemwise_into(name, fn, x, pd, out, workspace=ws)
+                arg = qd if fn == "ppf" else x
+                reps = 2 if (fn == "ppf" and label == "exact") else 5
+                for _ in range(1 if reps == 2 else 2):
+                    raw.elemwise_into(name, fn, arg, pd, out, workspace=ws)
                 ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
                 ev[0].record()
-                for _ in range(5):
-                    raw.elemwise_into(name, fn, x, pd, out, workspace=ws)
+                for _ in range(reps):
+                    raw.elemwise_into(name, fn, arg, pd, out, workspace=ws)
                 ev[1].record()
                 torch.cuda.synchronize()
-                res[label] = ev[0].elapsed_time(ev[1]) / 5
+                res[label] = ev[0].elapsed_time(ev[1]) / reps
                 res[label + "_sum"] = float(out.sum().item())
             finally:
                 L.m355_set_tab_min_n(old)

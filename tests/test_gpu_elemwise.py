@@ -621,19 +621,21 @@ def test_discrete_lookup_kernel(gpu, name, params):
         assert np.array_equal(tab, exact, equal_nan=True), (name, fn, q[~((tab == exact) | (np.isnan(tab) & np.isnan(exact)))][:5])
 
 
+@pytest.mark.parametrize("P", [48, 40])
 @pytest.mark.parametrize("name", ["poisson", "binomial", "negativebinomial", "betabinomial", "hypergeometric", "zi_poisson",
                                   "zi_binomial", "zi_negativebinomial"])
-def test_discrete_lookup_per_column(gpu, name):
-    """k_dcol_build + k_dcol (row-periodic parameters: one window of exact values per column in the call's workspace,
-    m355_elemwise.h), forced onto a small input: bit-identical to the exact kernels, for float64 and int64 observations,
-    counts inside and outside the windows, non-integers, NaN, infinities, and columns whose window does not fit or whose
-    parameters are out of domain (left to the exact bodies)."""
+def test_discrete_lookup_per_column(gpu, name, P):
+    """k_dcol_ranges + k_dcol_build + k_dcolg (P a multiple of 16: column groups, windows in LDS; quantiles by
+    find_ppf_discrete on the tabulated cdf / pmf) or k_dcol (any other P: cdf family only) -- row-periodic parameters, one
+    window of exact values per column in the call's workspace, m355_elemwise.h -- forced onto a small input: bit-identical
+    to the exact kernels, for float64 and int64 observations, counts inside and outside the windows, non-integers, NaN,
+    infinities, and columns whose window does not fit or whose parameters are out of domain (left to the exact bodies)."""
     from distributions_amd import _lib
 
     L = _lib.lib()
     rng = np.random.default_rng(43)
     m = mod(name)
-    P, R = 48, 700
+    R = 700
     pp = {
         "poisson": (np.concatenate([rng.uniform(0.2, 300.0, P - 2), [1e7, -1.0]]),),
         "binomial": (np.concatenate([rng.integers(1, 2000, P - 1), [5_000_000]]).astype(np.float64), rng.uniform(0.02, 0.98, P)),
@@ -662,12 +664,28 @@ def test_discrete_lookup_per_column(gpu, name):
                 L.m355_set_tab_min_n(old)
             assert tab.shape == (R, P)
             assert np.array_equal(tab, exact, equal_nan=True), (name, fn, np.argwhere(~((tab == exact) | (np.isnan(tab) & np.isnan(exact))))[:5])
+    # quantiles: the reference's search on the tabulated values -- the same iterates, bit for bit
+    q = rng.uniform(0, 1, (R, P))
+    q[:40] = np.exp(rng.uniform(-25, 0, (40, P)))
+    q[40:80] = 1 - np.exp(rng.uniform(-25, 0, (40, P)))
+    q[80, :8] = [np.nan, 0.0, 1.0, -0.5, 1.5, 1e-300, 1 - 2.0**-53, 0.5]
+    for fn in ("ppf", "isf"):
+        old = L.m355_set_tab_min_n(2**62)
+        try:
+            with np.errstate(all="ignore"):
+                exact = getattr(m, fn)(q, *pp)
+            L.m355_set_tab_min_n(1)
+            with np.errstate(all="ignore"):
+                tab = getattr(m, fn)(q, *pp)
+        finally:
+            L.m355_set_tab_min_n(old)
+        assert np.array_equal(tab, exact, equal_nan=True), (name, fn, np.argwhere(~((tab == exact) | (np.isnan(tab) & np.isnan(exact))))[:5])
     # the kernels really ran: after a call through the C-ABI with a NaN-filled workspace the column headers are in it
     import torch
 
     from distributions_amd import raw
 
-    ws = torch.full((8 + P * (2 + 2048),), float("nan"), dtype=torch.float64, device=gpu)
+    ws = torch.full((8 + P * (2 + 2 * 2048),), float("nan"), dtype=torch.float64, device=gpu)
     xd = torch.from_numpy(k).to(gpu)
     out = torch.empty_like(xd)
     old = L.m355_set_tab_min_n(1)
