@@ -386,6 +386,27 @@ def config10(torch, n):
             row[f"{fn}_evals_per_s"] = float(f"{n / (ms * 1e-3):.4g}")
         print(json.dumps(row), flush=True)
         del x, q, out
+    # row-periodic parameters (x of shape (R, 1024), parameters (1024,)): per-column windows in the call's workspace
+    # (k_dcolg, round 3); every 97th element against the oracle after the timed region
+    P = 1024
+    R = n // P
+    ws = raw.elemwise_workspace(dev)
+    lin = lambda a, b: torch.linspace(a, b, P, dtype=torch.float64, device=dev)
+    pcases = {"poisson": (lin(5.0, 200.0),), "binomial": (torch.full((P,), 1000.0, dtype=torch.float64, device=dev), lin(0.05, 0.95))}
+    for name, p in pcases.items():
+        x = _dispatch.rvs(name, tuple(a.reshape(1, P) for a in p), size=(R, P), random_state=6, as_torch=True).reshape(-1).contiguous()
+        q = torch.rand(R * P, dtype=torch.float64, device=dev, generator=g).clamp_(1e-6, 1 - 1e-6)
+        out = torch.empty(R * P, dtype=torch.float64, device=dev)
+        row = {"config": 10, "dist": name, "n": R * P, "layout": "params (1024,) row-periodic, int64 observations"}
+        for fn in ("cdf", "logcdf", "ppf"):
+            src = q if fn == "ppf" else x
+            ms = timed(torch, lambda: raw.elemwise_into(name, fn, src, p, out, workspace=ws), reps=3, warmup=1)
+            row[f"{fn}_ms"] = round(ms, 4)
+            row[f"{fn}_evals_per_s"] = float(f"{R * P / (ms * 1e-3):.4g}")
+            err, pts = spot_check(name, fn, src, out, p, cols=P)
+            row[f"{fn}_parity_max_err"], row["parity_points"] = err, pts
+        print(json.dumps(row), flush=True)
+        del x, q, out
 
 
 def main():
