@@ -583,6 +583,20 @@ M355_DEV double gammaincinv_p(double a, double p, double lga) {
 // logarithm of the larger is taken as log1p(-smaller): with log(1 - x) from the rounded 1 - x the term b log y carries
 // b * 1.1e-16 of absolute error (5.5e-11 at b = 5e5: measured on betainc(1/2, nu/2, .) at nu = 1e6).
 M355_HD double log_beta_kernel(double a, double b, double x, double y, double lbeta) {
+  if (a >= 10.0 && b >= 10.0) {
+    // both large: around the mode x0 = a / (a + b) the three terms a log x + b log y - lbeta are each of size
+    // (a + b) log 2 and cancel to O(1) -- 1e-11 of relative error in I_x at a + b = 1e5 (binomial.cdf at n = 9e4, round 3).
+    // With Stirling for B(a, b) and u1 = x / x0 - 1 = (b x - a y) / a, u2 = y / (1 - x0) - 1 = -(b x - a y) / b
+    // (a u1 + b u2 = 0 exactly) the kernel is
+    //   a (log1p(u1) - u1) + b (log1p(u2) - u2) + log(a b / (2 pi (a + b))) / 2 - S(a) - S(b) + S(a + b),
+    // every term of the size of the result.
+    const double t = b * x - a * y;
+    const double u1 = fdiv(t, a), u2 = fdiv(-t, b);
+    const double l1 = (u1 > -0.29 && u1 < 0.41) ? log1pmx(u1) : ((y < 0.5) ? flog1p(-y) : flog(x)) - flog(fdiv(a, a + b)) - u1;
+    const double l2 = (u2 > -0.29 && u2 < 0.41) ? log1pmx(u2) : ((x < 0.5) ? flog1p(-x) : flog(y)) - flog(fdiv(b, a + b)) - u2;
+    return (a * l1 + b * l2) + 0.5 * flog(fdiv(a * b, (a + b) * (2.0 * kPi))) -
+           ((stirling_corr(a) + stirling_corr(b)) - stirling_corr(a + b));
+  }
   const double lx = (y < 0.5) ? flog1p(-y) : flog(x);
   const double ly = (x < 0.5) ? flog1p(-x) : flog(y);
   return a * lx + b * ly - lbeta;
