@@ -4,13 +4,18 @@
 // is (global element index lo, hi, attempt, stream id), so a draw is a pure function of
 // (seed, stream, element index, parameters): the concatenated output is identical for any
 // partition of the index range over GPUs, and any range can be regenerated (resume) from its
-// offset.  Samplers: Box-Muller normal, Marsaglia-Tsang gamma (alpha < 1 by the U^(1/alpha)
+// offset.  Samplers: ziggurat normal (Box-Muller inside the composite samplers), Marsaglia-Tsang gamma (alpha < 1 by the U^(1/alpha)
 // boost), beta as a gamma ratio, Student t as normal / sqrt(chi2/nu), Poisson by sequential
 // inversion (mu < 10) or PTRS (Hoermann 1993), binomial by sequential inversion (n*min(p,q) < 10)
 // or BTRS (Hoermann 1993).  Rejection loops run per lane with a bounded attempt count.
 #pragma once
 #include "m355_dists4.h"
 #include "m355_sincoscoef.h"
+#ifdef M355_ZIGTAB_HEADER  // tools/zig_probe.hip: another layer count
+#include M355_ZIGTAB_HEADER
+#else
+#include "m355_zigtab.h"
+#endif
 
 namespace m355 {
 
@@ -19,6 +24,14 @@ struct Philox {
 };
 
 M355_HD unsigned mulhi32(unsigned a, unsigned b) { return (unsigned)(((unsigned long long)a * b) >> 32); }
+// a ^ b ^ c in one instruction (gfx950's v_bitop3_b32, truth table 0x96): half of Philox's forty xors
+M355_HD unsigned xor3(unsigned a, unsigned b, unsigned c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96);
+#else
+  return a ^ b ^ c;
+#endif
+}
 
 // One Philox4x32-10 block.
 M355_HD Philox philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1) {
@@ -29,9 +42,9 @@ M355_HD Philox philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3,
     const unsigned long long p1 = (unsigned long long)0xCD9E8D57u * c2;
     const unsigned hi0 = (unsigned)(p0 >> 32), lo0 = (unsigned)p0;
     const unsigned hi1 = (unsigned)(p1 >> 32), lo1 = (unsigned)p1;
-    c0 = hi1 ^ c1 ^ k0;
+    c0 = xor3(hi1, c1, k0);
     c1 = lo1;
-    c2 = hi0 ^ c3 ^ k1;
+    c2 = xor3(hi0, c3, k1);
     c3 = lo0;
     k0 += 0x9E3779B9u;
     k1 += 0xBB67AE85u;
@@ -142,6 +155,72 @@ M355_HD double cos_2pi_u32(unsigned w) {
 // costs no resolution -- which leaves word 3 to the caller (the acceptance uniform of a rejection sampler).
 M355_DEV double normal_single(const Philox& p) {
   return fsqrt(-2.0 * flog_tab(u53(p.c[0], p.c[1]))) * cos_2pi_u32(p.c[2]);
+}
+
+// Standard normal by the ziggurat (Marsaglia & Tsang 2000; 1024 layers, tables of m355_zigtab.h) -- numpy's Generator, which
+// the reference reaches through pt.random.normal (normal.py:66-67), samples the same way.  64 random bits per candidate:
+// bit 31 of `hi` is the sign, the ten bits below it the layer, and the 52 bits (hi & 0xfffff : lo) are the mantissa of d = 1 + u in
+// [1, 2); the candidate u x_i is accepted at once if d is below the layer's threshold 1 + x_(i+1) / x_i (99.6 % of the
+// candidates: one table read, one compare, one fma).  Otherwise zig_slow decides: the wedge of the other layers by
+// log(y) < -x^2 / 2 with y uniform between f(x_i) and f(x_(i+1)), the tail of layer 0 by Marsaglia's exponential
+// rejection.  A rejected candidate means a whole new attempt (new layer).
+// Counters: attempt 0 of elements 2k and 2k+1 is the two halves of block (k, 0); attempt a >= 1 of element g is words
+// 0-1 of block (g, a << 8); the extra uniforms of attempt a of element g come from blocks (g, (a << 8) + 1 + t), t the
+// iteration of the tail loop -- blocks with a non-zero third word belong to one element only.
+constexpr int kZigBits = kZigLayers == 256 ? 8 : kZigLayers == 512 ? 9 : kZigLayers == 1024 ? 10 : 11;
+static_assert(kZigLayers == (1 << kZigBits), "the layer is a bit field of the candidate's high word");
+M355_HD int zig_layer(unsigned hi) { return (int)((hi >> (31 - kZigBits)) & (unsigned)(kZigLayers - 1)); }
+M355_HD bool zig_fast(unsigned hi, unsigned lo, double thr, double xi, double& x) {
+  const double d = __builtin_bit_cast(double, ((unsigned long long)((hi & 0x000fffffu) | 0x3ff00000u) << 32) | (unsigned long long)lo);
+  const unsigned long long mag = __builtin_bit_cast(unsigned long long, __builtin_fma(d, xi, -xi));
+  x = __builtin_bit_cast(double, ((unsigned long long)((hi & 0x80000000u) | (unsigned)(mag >> 32)) << 32) | (mag & 0xffffffffull));
+  return d < thr;
+}
+struct ZigCtr {
+  unsigned long long g;  // global element index
+  unsigned stream, k0, k1;
+};
+M355_HD void zig_bits(const ZigCtr& z, unsigned a, unsigned& hi, unsigned& lo) {
+  if (a == 0u) {
+    const unsigned long long c = z.g >> 1;
+    const Philox p = philox4x32_10((unsigned)c, (unsigned)(c >> 32), 0u, z.stream, z.k0, z.k1);
+    hi = (z.g & 1ull) ? p.c[2] : p.c[0];
+    lo = (z.g & 1ull) ? p.c[3] : p.c[1];
+  } else {
+    const Philox p = philox4x32_10((unsigned)z.g, (unsigned)(z.g >> 32), a << 8, z.stream, z.k0, z.k1);
+    hi = p.c[0];
+    lo = p.c[1];
+  }
+}
+// the candidate x of layer `layer` failed the threshold test: accept (true; the tail replaces x) or reject
+M355_DEV bool zig_slow(const ZigCtr& z, unsigned a, int layer, double& x) {
+  if (layer == 0) {
+    for (unsigned t = 0;; ++t) {
+      const Philox e = philox4x32_10((unsigned)z.g, (unsigned)(z.g >> 32), (a << 8) + 1u + t, z.stream, z.k0, z.k1);
+      const double xx = -flog(u53(e.c[0], e.c[1])) * kZigRInv;
+      const double yy = -flog(u53(e.c[2], e.c[3]));
+      if (yy + yy > xx * xx || t >= 253u) {
+        x = __builtin_signbit(x) ? -(kZigR + xx) : kZigR + xx;
+        return true;
+      }
+    }
+  }
+  const Philox e = philox4x32_10((unsigned)z.g, (unsigned)(z.g >> 32), (a << 8) + 1u, z.stream, z.k0, z.k1);
+  const double f0 = kZigF[layer], f1 = kZigF[layer + 1];
+  const double y = __builtin_fma(u53(e.c[0], e.c[1]), f1 - f0, f0);
+  return flog(y) < -0.5 * x * x;
+}
+// per-lane loop (k_rvs and the host build); k_rvs_normal_zig runs the same attempts from a queue
+M355_DEV double sample_std_normal(const ZigCtr& z) {
+  double x = 0.0;
+  for (unsigned a = 0; a < (unsigned)kMaxAttempts; ++a) {
+    unsigned hi, lo;
+    zig_bits(z, a, hi, lo);
+    const int layer = zig_layer(hi);
+    if (zig_fast(hi, lo, kZigTab[2 * layer], kZigTab[2 * layer + 1], x)) break;
+    if (zig_slow(z, a, layer, x)) break;
+  }
+  return x;
 }
 
 // Uniform in (0, 1) on a 2^-44 grid from word 3 and the twelve low bits of word 0 that u53 drops (mantissa trick as in
@@ -383,19 +462,15 @@ M355_DEV double sample_binomial(RngState& st, double n, double p) {
 template <int D> M355_DEV double sample_one(unsigned long long idx, unsigned long long seed, unsigned stream,
                                            const double* p) {
   RngState st;
-  // Normal draws come in Box-Muller pairs: elements 2k and 2k+1 share block k (cos / sin branch).
-  const unsigned long long cidx = (D == M355_NORMAL) ? (idx >> 1) : idx;
-  st.idx_lo = (unsigned)cidx;
-  st.idx_hi = (unsigned)(cidx >> 32);
+  st.idx_lo = (unsigned)idx;
+  st.idx_hi = (unsigned)(idx >> 32);
   st.stream = stream;
   st.k0 = (unsigned)seed;
   st.k1 = (unsigned)(seed >> 32);
   st.attempt = 0;
   if constexpr (D == M355_NORMAL) {  // normal.py:66-67: mu + sigma * z
-    double u1, u2, z0, z1;
-    next_pair(st, u1, u2);
-    normal_pair(u1, u2, z0, z1);
-    return p[0] + p[1] * ((idx & 1ull) ? z1 : z0);
+    const ZigCtr z{idx, stream, st.k0, st.k1};
+    return __builtin_fma(p[1], sample_std_normal(z), p[0]);
   } else if constexpr (D == M355_GAMMA) {  // gamma.py:61-62: shape alpha, scale 1/beta
     return sample_std_gamma(st, p[0]) / p[1];
   } else if constexpr (D == M355_BETA) {  // beta.py:86-87

@@ -1,6 +1,8 @@
 // rvs kernels and their extern "C" entry point (declaration: include/m355_dist.h).
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "m355_elemwise.h"
 #include "m355_rng.h"
 
@@ -28,21 +30,118 @@ __global__ __launch_bounds__(kBlock) void k_rvs(GenericOps ops, void* __restrict
   }
 }
 
-// Normal with scalar parameters: each thread turns one Philox block into both Box-Muller branches
-// and stores 16 bytes (elements 2k, 2k+1); same values as k_rvs<M355_NORMAL>.
-__global__ __launch_bounds__(kBlock) void k_rvs_normal_pairs(double* __restrict__ out, long long npairs, double mu,
-                                                             double sigma, unsigned long long seed, unsigned stream,
-                                                             unsigned long long pair_offset) {
-  log_table_init();
-  for (long long k = (long long)blockIdx.x * kBlock + threadIdx.x; k < npairs; k += (long long)gridDim.x * kBlock) {
+// Normal with scalar parameters, fp64 output: the ziggurat of m355_rng.h with the rare path taken out of the loop.  A
+// wavefront covers 64 pairs of elements per trip: one Philox block per lane gives the candidates of elements 2k and
+// 2k + 1, the threshold test accepts 99.6 % of them at once (16-byte store when both halves pass; the table {threshold,
+// x_i} of 16 KiB in LDS), and a candidate that needs the wedge or the tail goes to the wavefront's queue in LDS as
+// (element, attempt number).  When 64 have gathered, each lane takes one entry, recomputes its block and runs zig_slow;
+// a rejected candidate comes back to the queue with the next attempt number.  Same draws as sample_std_normal (k_rvs).
+// Measured (tools/zig_probe.hip, 1e9 draws): the fast path alone 1.49 ms; with 256 layers (98.5 %) 86 % of the trips had
+// an open candidate and the queue cost 0.6 ms, hence the larger table.
+#ifdef M355_ZIG_BLOCK  // tools/zig_probe.hip
+constexpr int kZigBlock = M355_ZIG_BLOCK;
+#else
+constexpr int kZigBlock = 512;
+#endif
+constexpr int kZigQueue = 192;  // at most 63 waiting + 128 pushed by one trip; a test batch pushes back at most the 64 it took
+__global__ __launch_bounds__(kZigBlock) void k_rvs_normal_zig(double* __restrict__ out, long long npairs, double mu,
+                                                              double sigma, unsigned long long seed, unsigned stream,
+                                                              unsigned long long pair_offset) {
+  __shared__ double tab[2 * kZigLayers];
+  __shared__ unsigned long long q[kZigBlock / 64][kZigQueue];  // element index relative to `out` | attempt number << 56
+  for (int i = threadIdx.x; i < 2 * kZigLayers; i += kZigBlock) tab[i] = kZigTab[i];
+  __syncthreads();
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const long long wave = (long long)blockIdx.x * (kZigBlock / 64) + wv;
+  const long long nwaves = (long long)gridDim.x * (kZigBlock / 64);
+  const unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
+  int queued = 0;  // wave-uniform
+  auto push = [&](bool want, unsigned long long entry) {
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(want);
+    if (want) q[wv][queued + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u))] = entry;
+    queued += __popcll(m);
+  };
+  // entries [first, first + cnt) of the queue, one per lane (the caller has already taken them off `queued`)
+  auto test = [&](int first, int cnt) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    unsigned long long entry = 0;
+    if (lane < cnt) entry = q[wv][first + lane];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();  // every entry is read before push() writes over the same slots
+    bool again = false;
+    if (lane < cnt) {
+      const unsigned long long e = entry & 0x00ffffffffffffffull;
+      const unsigned a = (unsigned)(entry >> 56);
+      const ZigCtr z{2ull * pair_offset + e, stream, k0, k1};
+      unsigned hi, lo;
+      zig_bits(z, a, hi, lo);
+      const int layer = zig_layer(hi);
+      double x;
+      bool ok = zig_fast(hi, lo, tab[2 * layer], tab[2 * layer + 1], x);
+      if (!ok) ok = zig_slow(z, a, layer, x);
+      if (ok || a + 1u >= (unsigned)kMaxAttempts) out[e] = __builtin_fma(sigma, x, mu);
+      else again = true;
+    }
+    push(again, entry + (1ull << 56));
+  };
+  // one trip: pair k of this lane (tail: only where `act`)
+  auto trip = [&](long long k, auto tail, bool act) {
     const unsigned long long c = pair_offset + (unsigned long long)k;
-    const Philox p = philox4x32_10((unsigned)c, (unsigned)(c >> 32), 0u, stream, (unsigned)seed, (unsigned)(seed >> 32));
-    double z0, z1;
-    normal_pair(u53(p.c[0], p.c[1]), u53(p.c[2], p.c[3]), z0, z1);
+    const Philox p = philox4x32_10((unsigned)c, (unsigned)(c >> 32), 0u, stream, k0, k1);
+    const int l0 = zig_layer(p.c[0]), l1 = zig_layer(p.c[2]);
+    double x0, x1;
+    bool f0 = zig_fast(p.c[0], p.c[1], tab[2 * l0], tab[2 * l0 + 1], x0);
+    bool f1 = zig_fast(p.c[2], p.c[3], tab[2 * l1], tab[2 * l1 + 1], x1);
     d2_t v;
-    v.x = mu + sigma * z0;
-    v.y = mu + sigma * z1;
-    __builtin_nontemporal_store(v, reinterpret_cast<d2_t*>(out + 2 * k));
+    v.x = __builtin_fma(sigma, x0, mu);
+    v.y = __builtin_fma(sigma, x1, mu);
+    double* dst = out + 2 * k;
+    if constexpr (decltype(tail)::value) {
+      if (!act) return;  // (the last trip of one wavefront: nothing follows but the final tests, which are wave-wide again)
+    }
+    // one queue entry per lane in the common case; a lane with both halves open (2e-4) adds the second one
+#if defined(M355_ZIG_VARIANT) && (M355_ZIG_VARIANT == 1 || M355_ZIG_VARIANT == 2)  // tools/zig_probe.hip: no queue
+    if (M355_ZIG_VARIANT == 1) __builtin_nontemporal_store(v, reinterpret_cast<d2_t*>(dst));
+    else *reinterpret_cast<d2_t*>(dst) = v;
+    return;
+#endif
+    const unsigned long long m0 = __builtin_amdgcn_ballot_w64(!f0), m1 = __builtin_amdgcn_ballot_w64(!f1);
+    const unsigned long long any = m0 | m1;
+#if defined(M355_ZIG_VARIANT) && M355_ZIG_VARIANT == 3  // tools/zig_probe.hip: no holes (timing only: the later store races)
+    __builtin_nontemporal_store(v, reinterpret_cast<d2_t*>(dst));
+    if (!(f0 & f1)) {
+      q[wv][queued + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(any >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)any, 0u))] =
+          2ull * (unsigned long long)k + (f0 ? 1ull : 0ull);
+    }
+    queued += __popcll(any);
+    if ((m0 & m1) != 0ull) push(!f0 & !f1, 2ull * (unsigned long long)k + 1ull);
+    return;
+#endif
+    if (f0 & f1) {
+      __builtin_nontemporal_store(v, reinterpret_cast<d2_t*>(dst));
+    } else {
+      if (f0) dst[0] = v.x;
+      if (f1) dst[1] = v.y;
+      q[wv][queued + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(any >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)any, 0u))] =
+          2ull * (unsigned long long)k + (f0 ? 1ull : 0ull);
+    }
+    queued += __popcll(any);
+    if ((m0 & m1) != 0ull) push(!f0 & !f1, 2ull * (unsigned long long)k + 1ull);
+  };
+  const long long nfull = npairs >> 6;
+  for (long long t = wave; t < nfull; t += nwaves) {
+    trip(t * 64 + lane, std::false_type{}, true);
+    while (queued >= 64) {  // (back to at most 63 before the next trip adds up to 128)
+      queued -= 64;
+      test(queued, 64);
+    }
+  }
+  if ((npairs & 63) != 0 && wave == nfull % nwaves) trip(nfull * 64 + lane, std::true_type{}, nfull * 64 + lane < npairs);
+  while (queued > 0) {
+    const int cnt = queued < 64 ? queued : 64;
+    queued -= cnt;
+    test(queued, cnt);
   }
 }
 
@@ -345,9 +444,9 @@ extern "C" int m355_rvs_impl(int dist, int out_dtype, long long n, const m355::G
   if (dist == M355_NORMAL && out_dtype == M355_F64 && ops->p[0].ptr == nullptr && ops->p[1].ptr == nullptr &&
       (offset & 1ull) == 0 && aligned(out, 16) && n >= 2) {
     const long long npairs = n / 2;
-    const long long want = (npairs + kBlock - 1) / kBlock;
-    const int blocks = (int)(want > kMaxBlocks ? kMaxBlocks : want);
-    hipLaunchKernelGGL(k_rvs_normal_pairs, dim3(blocks), dim3(kBlock), 0, s, static_cast<double*>(out), npairs,
+    const long long want = (npairs + kZigBlock - 1) / kZigBlock;
+    const int blocks = (int)(want > kMaxBlocks / 2 ? kMaxBlocks / 2 : want);
+    hipLaunchKernelGGL(k_rvs_normal_zig, dim3(blocks), dim3(kZigBlock), 0, s, static_cast<double*>(out), npairs,
                        ops->p[0].scalar, ops->p[1].scalar, seed, stream_id, offset >> 1);
     int rc = (int)hipGetLastError();
     if (rc != 0 || (n & 1) == 0) return rc;

@@ -178,7 +178,58 @@ def test_host_sampler_partition_invariance(hostlib):
     assert np.array_equal(a[501:], b)
 
 
+def _ziggurat_checks(x):
+    """Shape of a standard-normal sample beyond what one KS statistic sees: 400 equiprobable cells (the wedges of the
+    1024 layers are 0.4 % of the draws, spread over the whole range) and the tail beyond the ziggurat's r = 4.0388 (its own
+    sampler: Marsaglia's exponential rejection)."""
+    n = x.size
+    edges = stats.norm.ppf(np.linspace(0.0, 1.0, 401))
+    counts = np.histogram(x, bins=edges)[0]
+    assert stats.chisquare(counts).pvalue > 1e-4
+    r = 4.0388498461095045
+    for lo in (r, 4.5, 5.0):
+        expect = 2.0 * stats.norm.sf(lo) * n
+        got = np.count_nonzero(np.abs(x) > lo)
+        assert abs(got - expect) <= 5.0 * np.sqrt(expect) + 1.0, (lo, got, expect)
+    assert abs(np.count_nonzero(x > 0) - 0.5 * n) <= 5.0 * np.sqrt(0.25 * n)
+    tail = np.abs(x[np.abs(x) > r])
+    if tail.size > 200:  # conditional law of the tail: P(|X| > t | |X| > r)
+        assert stats.kstest(tail, lambda t: 1.0 - stats.norm.sf(t) / stats.norm.sf(r)).pvalue > 1e-4
+
+
+def test_host_normal_ziggurat_shape(hostlib):
+    x = host_rvs(hostlib, "normal", 6_000_000, (0.0, 1.0))
+    _ziggurat_checks(x)
+    # element 2k + 1 reads the second half of the block of element 2k; a rejected candidate moves to the element's own blocks
+    a = host_rvs(hostlib, "normal", 20_001, (1.5, 0.25), offset=7)
+    b = host_rvs(hostlib, "normal", 20_008, (1.5, 0.25), offset=0)
+    assert np.array_equal(a, b[7:])
+
+
 # ------------------------------------------------------------------------------------------- GPU
+@pytest.mark.gpu
+def test_gpu_normal_ziggurat_queue_equals_per_lane_loop(gpu, hostlib):
+    """k_rvs_normal_zig (scalar parameters: candidates that fail the threshold test wait in a queue in LDS) and the
+    per-lane loop of k_rvs (array parameters) give bit-identical draws, for any split of the range and odd lengths;
+    shape checks of the sample, tail included, at 2e8 draws."""
+    from distributions_amd import normal
+
+    n = 1_000_003
+    a = normal.rvs(0.5, 2.0, size=n, random_state=13)
+    b = normal.rvs(np.full(n, 0.5), np.full(n, 2.0), size=n, random_state=13)
+    assert np.array_equal(a, b)
+    for h in (123_456, 123_457):  # (an odd offset takes the per-lane kernel for the second part)
+        c = np.concatenate([normal.rvs(0.5, 2.0, size=h, random_state=(13, 0)), normal.rvs(0.5, 2.0, size=n - h, random_state=(13, h))])
+        assert np.array_equal(a, c)
+    # (the host build's log differs in the last bits: the handful of tail draws may, too)
+    assert np.allclose(a[:200_000], host_rvs(hostlib, "normal", 200_000, (0.5, 2.0), seed=13), rtol=1e-12, atol=0.0)
+    for size in (1, 2, 63, 127, 129):
+        assert np.array_equal(normal.rvs(0.5, 2.0, size=size, random_state=13), a[:size])
+    x = normal.rvs(0.0, 1.0, size=200_000_000, random_state=14)
+    assert np.isfinite(x).all() and np.abs(x).max() < 7.5
+    _ziggurat_checks(x)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("name, params, d", CONT, ids=[f"{c[0]}-{c[1]}" for c in CONT])
 def test_gpu_rvs_continuous(gpu, hostlib, name, params, d):
