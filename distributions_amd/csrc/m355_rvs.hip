@@ -428,6 +428,80 @@ template <int D> bool try_rvs_mt(const GenericOps& ops, void* out, int odt, long
   return true;
 }
 
+// Discrete family with scalar parameters: inversion on the cdf tabulated over the family's window (m355_rng.h: inv_draw).
+// Every workgroup evaluates the window itself (len <= 2048 exact cdf values over 512 threads) and builds the guide table;
+// then one Philox block per lane and trip gives the draws of elements 2c and 2c + 1 of the global stream (16-byte store
+// when the call starts at an even element and `out` allows it).  No rejection, no divergence: ~30 operations per draw.
+typedef long long ll2_t __attribute__((ext_vector_type(2)));
+template <int D> bool inv_params_ok(const double* p);  // parameter sets the tabulated path takes (the rest: per-lane samplers)
+template <> bool inv_params_ok<M355_POISSON>(const double* p) { return p[0] > 0.0 && p[0] < kInf; }
+template <> bool inv_params_ok<M355_BINOMIAL>(const double* p) {
+  return p[0] >= 1.0 && p[0] < kInf && p[0] == __builtin_floor(p[0]) && p[1] > 0.0 && p[1] < 1.0;
+}
+constexpr int kInvBlock = 512;
+constexpr int kInvMaxBlocks = 1024;  // (each workgroup pays for the whole table)
+template <int D>
+__global__ __launch_bounds__(kInvBlock) void k_rvs_inv(void* __restrict__ out, int odt, long long n,
+                                                       const typename Dist<D>::K k, double lo, int len,
+                                                       unsigned long long seed, unsigned stream, unsigned long long offset) {
+  using DD = Dist<D>;
+  __shared__ double c[kDTabMax];
+  __shared__ unsigned short g[kInvGuide + 2];
+  if constexpr (uses_log_table<DD>::value) log_table_init();
+  for (int j = threadIdx.x; j < len; j += kInvBlock) c[j] = DD::dtab_cdf(lo + (double)j, k);
+  __syncthreads();
+  for (int j = threadIdx.x; j <= kInvGuide; j += kInvBlock) g[j] = (unsigned short)(j < kInvGuide ? inv_guide(c, len, j) : len - 1);
+  __syncthreads();
+  const unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
+  const unsigned long long first = offset >> 1;  // block of the call's first element
+  const long long npairs = (long long)(((offset + (unsigned long long)n - 1ull) >> 1) - first) + 1;
+  const long long shift = (long long)(offset & 1ull);  // element 2 * pair - shift of `out` is the first half of the pair
+  const bool wide = shift == 0 && odt != M355_F32 && (reinterpret_cast<unsigned long long>(out) & 15ull) == 0ull;
+  for (long long pr = (long long)blockIdx.x * kInvBlock + threadIdx.x; pr < npairs; pr += (long long)gridDim.x * kInvBlock) {
+    const unsigned long long cc = first + (unsigned long long)pr;
+    const Philox ph = philox4x32_10((unsigned)cc, (unsigned)(cc >> 32), 0u, stream, k0, k1);
+    const double v0 = inv_draw<D>(c, g, len, lo, ph.c[0], ph.c[1], k);
+    const double v1 = inv_draw<D>(c, g, len, lo, ph.c[2], ph.c[3], k);
+    const long long e0 = 2 * pr - shift, e1 = e0 + 1;
+    if (wide && e1 < n) {
+      if (odt == M355_I64) {
+        ll2_t w;
+        w.x = (long long)v0;
+        w.y = (long long)v1;
+        __builtin_nontemporal_store(w, reinterpret_cast<ll2_t*>(static_cast<long long*>(out) + e0));
+      } else {
+        d2_t w;
+        w.x = v0;
+        w.y = v1;
+        __builtin_nontemporal_store(w, reinterpret_cast<d2_t*>(static_cast<double*>(out) + e0));
+      }
+    } else {
+      if (e0 >= 0) store_draw(out, odt, e0, v0);
+      if (e1 < n) store_draw(out, odt, e1, v1);
+    }
+  }
+}
+template <int D> bool try_rvs_inv(const GenericOps& ops, void* out, int odt, long long n, unsigned long long seed,
+                                  unsigned stream, unsigned long long offset, hipStream_t s, int* rc) {
+  using DD = Dist<D>;
+  double pp[kMaxParams] = {0.0, 0.0, 0.0, 0.0};
+  for (int q = 0; q < DD::NP; ++q) {
+    if (ops.p[q].ptr != nullptr) return false;
+    pp[q] = ops.p[q].scalar;
+  }
+  if (n < 1 || !inv_params_ok<D>(pp)) return false;
+  const typename DD::K k = DD::derive(pp);
+  double lo = 0.0;
+  int len = 0;
+  if (!DD::dtab_range(k, lo, len) || len < 1) return false;
+  const long long npairs = n / 2 + 1;
+  const long long want = (npairs + 4 * kInvBlock - 1) / (4 * kInvBlock);  // >= 8 draws per thread
+  const int blocks = (int)(want > kInvMaxBlocks ? kInvMaxBlocks : want);
+  hipLaunchKernelGGL((k_rvs_inv<D>), dim3(blocks), dim3(kInvBlock), 0, s, out, odt, n, k, lo, len, seed, stream, offset);
+  *rc = (int)hipGetLastError();
+  return true;
+}
+
 template <int D> int launch_rvs(const GenericOps& ops, void* out, int odt, long long n, unsigned long long seed,
                                 unsigned stream, unsigned long long offset, hipStream_t s) {
   const long long want = (n + kBlock - 1) / kBlock;
@@ -453,6 +527,13 @@ extern "C" int m355_rvs_impl(int dist, int out_dtype, long long n, const m355::G
     // odd tail element
     return launch_rvs<M355_NORMAL>(*ops, static_cast<double*>(out) + (n - 1), out_dtype, 1, seed, stream_id,
                                    offset + (unsigned long long)(n - 1), s);
+  }
+  {  // discrete families with scalar parameters whose window fits: inversion, for every n (one stream per parameter set)
+    int rc = 0;
+    bool done = false;
+    if (dist == M355_POISSON) done = try_rvs_inv<M355_POISSON>(*ops, out, out_dtype, n, seed, stream_id, offset, s, &rc);
+    else if (dist == M355_BINOMIAL) done = try_rvs_inv<M355_BINOMIAL>(*ops, out, out_dtype, n, seed, stream_id, offset, s, &rc);
+    if (done) return rc;
   }
   const bool scalar2 = ops->p[0].ptr == nullptr && ops->p[1].ptr == nullptr;
   const double q0 = ops->p[0].scalar, q1 = ops->p[1].scalar;

@@ -3,6 +3,7 @@
 // GPU is attached.  The hardware seeds (v_rcp_f64, v_frexp_*) and the device libm (lgamma, exp,
 // erfc) are replaced by host equivalents, so this is NOT the parity test: parity is tests -m gpu.
 #include <type_traits>
+#include <vector>
 
 #include "../../distributions_amd/csrc/m355_dist_list.h"
 #include "../../distributions_amd/csrc/m355_dists4.h"
@@ -119,6 +120,36 @@ extern "C" int hm_rvs(int dist, long n, const double* p, unsigned long long seed
   case ID: rvs_loop<ID>(n, p, seed, stream, offset, out); return 0;
     M355_DIST_LIST(HM_RVS_CASE)
 #undef HM_RVS_CASE
+  }
+  return -1;
+}
+
+// Discrete families with scalar parameters: inversion on the tabulated cdf (csrc/m355_rng.h inv_draw, the body of
+// k_rvs_inv).  Returns -2 where the family's window does not fit (the GPU library then takes its per-lane samplers).
+template <int D> static int rvs_inv_loop(long n, const double* p, unsigned long long seed, unsigned stream,
+                                         unsigned long long offset, double* out) {
+  using DD = Dist<D>;
+  const auto k = DD::derive(p);
+  double lo = 0.0;
+  int len = 0;
+  if (!DD::dtab_range(k, lo, len) || len < 1) return -2;
+  std::vector<double> c(len);
+  std::vector<unsigned short> g(kInvGuide + 1);
+  for (int j = 0; j < len; ++j) c[j] = DD::dtab_cdf(lo + (double)j, k);
+  for (int j = 0; j <= kInvGuide; ++j) g[j] = (unsigned short)(j < kInvGuide ? inv_guide(c.data(), len, j) : len - 1);
+  for (long i = 0; i < n; ++i) {
+    const unsigned long long e = offset + (unsigned long long)i, cc = e >> 1;
+    const Philox ph = philox4x32_10((unsigned)cc, (unsigned)(cc >> 32), 0u, stream, (unsigned)seed, (unsigned)(seed >> 32));
+    out[i] = (e & 1ull) ? inv_draw<D>(c.data(), g.data(), len, lo, ph.c[2], ph.c[3], k)
+                        : inv_draw<D>(c.data(), g.data(), len, lo, ph.c[0], ph.c[1], k);
+  }
+  return 0;
+}
+extern "C" int hm_rvs_inv(int dist, long n, const double* p, unsigned long long seed, unsigned stream,
+                          unsigned long long offset, double* out) {
+  switch (dist) {
+    case M355_POISSON: return rvs_inv_loop<M355_POISSON>(n, p, seed, stream, offset, out);
+    case M355_BINOMIAL: return rvs_inv_loop<M355_BINOMIAL>(n, p, seed, stream, offset, out);
   }
   return -1;
 }

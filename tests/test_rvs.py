@@ -26,7 +26,7 @@ CONT = [
     ("beta", (0.5, 0.7), stats.beta(0.5, 0.7)),
     ("studentt", (5.0, 0.0, 2.0), stats.t(5, 0, 2)),
 ]
-DISC = [
+DISC = [  # (comments: the per-lane sampler's branch; with scalar parameters the library inverts the tabulated cdf instead)
     ("poisson", (100.0,), stats.poisson(100)),      # PTRS
     ("poisson", (4.0,), stats.poisson(4)),          # sequential inversion
     ("poisson", (10.0,), stats.poisson(10)),        # PTRS at its lower edge
@@ -34,6 +34,11 @@ DISC = [
     ("binomial", (10, 0.3), stats.binom(10, 0.3)),      # inversion
     ("binomial", (100, 0.9), stats.binom(100, 0.9)),    # p > 1/2 flip
     ("binomial", (40, 0.25), stats.binom(40, 0.25)),    # BTRS at n p = 10
+]
+DISC_BIG = [  # windows beyond 2048 integers: the rejection samplers also with scalar parameters (k_rvs_compact)
+    ("poisson", (20000.0,), stats.poisson(20000)),
+    ("binomial", (200000, 0.3), stats.binom(200000, 0.3)),
+    ("binomial", (500000, 0.9), stats.binom(500000, 0.9)),
 ]
 
 
@@ -45,6 +50,27 @@ def host_rvs(lib, name, n, params, seed=20260313, stream=None, offset=0):
     stream = DIST[name] if stream is None else stream
     assert lib.hm_rvs(DIST[name], n, p.ctypes.data_as(_dp), seed, stream, offset, out.ctypes.data_as(_dp)) == 0
     return out
+
+
+INV_DISTS = ("poisson", "binomial")  # scalar parameters: inversion on the tabulated cdf (k_rvs_inv) where the window fits
+
+
+def host_rvs_inv(lib, name, n, params, seed=20260313, stream=None, offset=0):
+    """Host build of k_rvs_inv's body; None where the family's window does not fit (the library then samples per lane)."""
+    lib.hm_rvs_inv.argtypes = [ctypes.c_int, ctypes.c_long, _dp, ctypes.c_ulonglong, ctypes.c_uint,
+                               ctypes.c_ulonglong, _dp]
+    p = np.array(list(params) + [0, 0, 0, 0], dtype=np.float64)[:4].copy()
+    out = np.empty(n)
+    stream = DIST[name] if stream is None else stream
+    rc = lib.hm_rvs_inv(DIST[name], n, p.ctypes.data_as(_dp), seed, stream, offset, out.ctypes.data_as(_dp))
+    assert rc in (0, -2)
+    return out if rc == 0 else None
+
+
+def host_rvs_scalar(lib, name, n, params, **kw):
+    """What the library draws for SCALAR parameters: the inversion sampler for INV_DISTS, else the per-lane sampler."""
+    x = host_rvs_inv(lib, name, n, params, **kw) if name in INV_DISTS else None
+    return host_rvs(lib, name, n, params, **kw) if x is None else x
 
 
 def chi2_pvalue(x, d):
@@ -97,12 +123,31 @@ def test_host_sampler_continuous_ks(hostlib, name, params, d):
     assert stats.ks_2samp(x, ref).pvalue > 1e-3
 
 
-@pytest.mark.parametrize("name, params, d", DISC, ids=[f"{c[0]}-{c[1]}" for c in DISC])
+@pytest.mark.parametrize("name, params, d", DISC + DISC_BIG, ids=[f"{c[0]}-{c[1]}" for c in DISC + DISC_BIG])
 def test_host_sampler_discrete_chi2(hostlib, name, params, d):
     x = host_rvs(hostlib, name, 400_000, params)
     assert np.all(x == np.floor(x)) and x.min() >= 0
     assert chi2_pvalue(x, d) > 1e-3
     assert moments_ok(x, d)
+
+
+@pytest.mark.parametrize("name, params, d", DISC + [("poisson", (0.05,), stats.poisson(0.05)), ("poisson", (5000.0,), stats.poisson(5000)),
+                                                    ("binomial", (1, 0.3), stats.binom(1, 0.3)), ("binomial", (2000, 0.999), stats.binom(2000, 0.999))],
+                         ids=lambda v: str(v) if isinstance(v, (str, tuple)) else "")
+def test_host_inversion_sampler(hostlib, name, params, d):
+    """The sampler for scalar parameters (body of k_rvs_inv): chi-square and moments, draw == ppf(u) by construction
+    (smallest k with cdf(k) >= u), any split of the stream concatenates to the same draws."""
+    x = host_rvs_inv(hostlib, name, 1_000_000, params)
+    assert x is not None and np.all(x == np.floor(x)) and x.min() >= 0
+    assert chi2_pvalue(x, d) > 1e-3
+    assert moments_ok(x, d)
+    parts = np.concatenate([host_rvs_inv(hostlib, name, m, params, offset=o) for o, m in ((0, 7), (7, 1000), (1007, 4993))])
+    assert np.array_equal(x[:6000], parts)
+
+
+def test_host_inversion_sampler_window(hostlib):
+    assert host_rvs_inv(hostlib, "poisson", 10, (20000.0,)) is None  # 23 sd + 52 > 2048 integers
+    assert host_rvs_inv(hostlib, "binomial", 10, (200000, 0.3)) is None
 
 
 class OracleDiscrete:
@@ -260,8 +305,12 @@ def test_gpu_rvs_discrete(gpu, hostlib, name, params, d):
     assert x.dtype == np.int64 and x.min() >= 0
     assert chi2_pvalue(x, d) > 1e-3
     assert moments_ok(x.astype(np.float64), d)
-    h = host_rvs(hostlib, name, 200_000, params)
+    h = host_rvs_scalar(hostlib, name, 200_000, params)
     assert (x[:200_000] == h).mean() > 0.9999
+    # parameters as arrays: the per-lane samplers (PTRS / BTRS / sequential inversion)
+    xa = m.rvs(*[np.full(400_000, p, dtype=np.float64) for p in params], size=400_000, random_state=20260313)
+    assert xa.dtype == np.int64 and chi2_pvalue(xa, d) > 1e-3
+    assert (xa[:200_000] == host_rvs(hostlib, name, 200_000, params)).mean() > 0.9999
 
 
 @pytest.mark.gpu
@@ -295,11 +344,35 @@ def test_gpu_rvs_semantics(gpu):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name, params", [("poisson", (100.0,)), ("poisson", (10.0,)), ("binomial", (1000, 0.3)),
-                                          ("binomial", (100, 0.9))])
+@pytest.mark.parametrize("name, params, d", DISC + [("poisson", (0.05,), stats.poisson(0.05)), ("poisson", (5000.0,), stats.poisson(5000)),
+                                                    ("binomial", (2000, 0.999), stats.binom(2000, 0.999))],
+                         ids=lambda v: str(v) if isinstance(v, (str, tuple)) else "")
+def test_gpu_inversion_sampler(gpu, hostlib, name, params, d):
+    """k_rvs_inv (scalar parameters): the host build's draws, any split of the range over calls (odd offsets: the second
+    half of a Philox block first), sizes down to one element, and the law at 2e7 draws."""
+    import importlib
+
+    m = importlib.import_module(f"distributions_amd.{name}")
+    n = 300_007
+    a = m.rvs(*params, size=n, random_state=11)
+    assert a.dtype == np.int64
+    h = host_rvs_inv(hostlib, name, n, params, seed=11)
+    assert h is not None and (a == h).mean() > 0.9999
+    for cut in (123_456, 123_457):
+        c = np.concatenate([m.rvs(*params, size=cut, random_state=(11, 0)), m.rvs(*params, size=n - cut, random_state=(11, cut))])
+        assert np.array_equal(a, c)
+    for size in (1, 2, 3, 511, 1025):
+        assert np.array_equal(m.rvs(*params, size=size, random_state=11), a[:size])
+        assert np.array_equal(m.rvs(*params, size=size, random_state=(11, 77)), a[77:77 + size])
+    x = m.rvs(*params, size=20_000_000, random_state=12)
+    assert chi2_pvalue(x, d) > 1e-4 and moments_ok(x.astype(np.float64), d)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name, params", [(c[0], c[1]) for c in DISC_BIG] + [("poisson", (1.0e6,))])
 def test_gpu_compaction_equals_per_lane_loop(gpu, name, params):
-    """The wavefront-compacting kernel (scalar parameters) and the per-lane rejection loop (array
-    parameters) give bit-identical draws: a draw depends only on (seed, stream, element, attempt)."""
+    """The wavefront-compacting kernel (scalar parameters whose window is too long for k_rvs_inv) and the per-lane
+    rejection loop (array parameters) give bit-identical draws: a draw depends only on (seed, stream, element, attempt)."""
     import importlib
 
     m = importlib.import_module(f"distributions_amd.{name}")
