@@ -498,6 +498,28 @@ template <int D> M355_DEV_HEAVY double inv_beyond(double v, double u, const type
   for (int step = 0; step < 4096 && Dist<D>::dtab_cdf(v, k) < u; ++step) v += 1.0;
   return v;
 }
+// the families sampled this way, and the parameter sets they take (anything else: the per-lane samplers of sample_one)
+template <int D> struct InvFamily { static constexpr bool value = false; };
+#define M355_INV_FAMILY(ID, COND)                                  \
+  template <> struct InvFamily<ID> {                               \
+    static constexpr bool value = true;                            \
+    static M355_HD bool ok(const double* p) { return COND; }       \
+  };
+M355_HD bool inv_count(double n) { return n >= 1.0 && n < kInf && n == __builtin_floor(n); }
+M355_HD bool inv_prob(double p) { return p > 0.0 && p < 1.0; }
+M355_INV_FAMILY(M355_POISSON, p[0] > 0.0 && p[0] < kInf)
+M355_INV_FAMILY(M355_BINOMIAL, inv_count(p[0]) && inv_prob(p[1]))
+M355_INV_FAMILY(M355_NEGATIVEBINOMIAL, p[0] > 0.0 && p[0] < kInf && inv_prob(p[1]))
+M355_INV_FAMILY(M355_BETABINOMIAL, inv_count(p[0]) && p[1] > 0.0 && p[1] < kInf && p[2] > 0.0 && p[2] < kInf)
+M355_INV_FAMILY(M355_HYPERGEOMETRIC, inv_count(p[0]) && inv_count(p[1]) && inv_count(p[2]) && p[1] <= p[0] && p[2] <= p[0])
+M355_INV_FAMILY(M355_ZI_POISSON, p[0] > 0.0 && p[0] <= 1.0 && p[1] > 0.0 && p[1] < kInf)
+M355_INV_FAMILY(M355_ZI_BINOMIAL, p[0] > 0.0 && p[0] <= 1.0 && inv_count(p[1]) && inv_prob(p[2]))
+M355_INV_FAMILY(M355_ZI_NEGATIVEBINOMIAL, p[0] > 0.0 && p[0] <= 1.0 && p[1] > 0.0 && p[1] < kInf && inv_prob(p[2]))
+#undef M355_INV_FAMILY
+#define M355_INV_LIST(X)                                                                                        \
+  X(M355_POISSON) X(M355_BINOMIAL) X(M355_NEGATIVEBINOMIAL) X(M355_BETABINOMIAL) X(M355_HYPERGEOMETRIC) \
+  X(M355_ZI_POISSON) X(M355_ZI_BINOMIAL) X(M355_ZI_NEGATIVEBINOMIAL)
+
 template <int D>
 M355_DEV double inv_draw(const double* c, const unsigned short* g, int len, double lo, unsigned hi, unsigned lw,
                          const typename Dist<D>::K& k) {

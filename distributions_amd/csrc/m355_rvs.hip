@@ -433,11 +433,6 @@ template <int D> bool try_rvs_mt(const GenericOps& ops, void* out, int odt, long
 // then one Philox block per lane and trip gives the draws of elements 2c and 2c + 1 of the global stream (16-byte store
 // when the call starts at an even element and `out` allows it).  No rejection, no divergence: ~30 operations per draw.
 typedef long long ll2_t __attribute__((ext_vector_type(2)));
-template <int D> bool inv_params_ok(const double* p);  // parameter sets the tabulated path takes (the rest: per-lane samplers)
-template <> bool inv_params_ok<M355_POISSON>(const double* p) { return p[0] > 0.0 && p[0] < kInf; }
-template <> bool inv_params_ok<M355_BINOMIAL>(const double* p) {
-  return p[0] >= 1.0 && p[0] < kInf && p[0] == __builtin_floor(p[0]) && p[1] > 0.0 && p[1] < 1.0;
-}
 constexpr int kInvBlock = 512;
 constexpr int kInvMaxBlocks = 1024;  // (each workgroup pays for the whole table)
 template <int D>
@@ -489,7 +484,7 @@ template <int D> bool try_rvs_inv(const GenericOps& ops, void* out, int odt, lon
     if (ops.p[q].ptr != nullptr) return false;
     pp[q] = ops.p[q].scalar;
   }
-  if (n < 1 || !inv_params_ok<D>(pp)) return false;
+  if (n < 1 || !InvFamily<D>::ok(pp)) return false;
   const typename DD::K k = DD::derive(pp);
   double lo = 0.0;
   int len = 0;
@@ -531,8 +526,13 @@ extern "C" int m355_rvs_impl(int dist, int out_dtype, long long n, const m355::G
   {  // discrete families with scalar parameters whose window fits: inversion, for every n (one stream per parameter set)
     int rc = 0;
     bool done = false;
-    if (dist == M355_POISSON) done = try_rvs_inv<M355_POISSON>(*ops, out, out_dtype, n, seed, stream_id, offset, s, &rc);
-    else if (dist == M355_BINOMIAL) done = try_rvs_inv<M355_BINOMIAL>(*ops, out, out_dtype, n, seed, stream_id, offset, s, &rc);
+    switch (dist) {
+#define M355_INV_CASE(ID) \
+  case ID: done = try_rvs_inv<ID>(*ops, out, out_dtype, n, seed, stream_id, offset, s, &rc); break;
+      M355_INV_LIST(M355_INV_CASE)
+#undef M355_INV_CASE
+      default: break;
+    }
     if (done) return rc;
   }
   const bool scalar2 = ops->p[0].ptr == nullptr && ops->p[1].ptr == nullptr;

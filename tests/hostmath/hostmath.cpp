@@ -129,6 +129,7 @@ extern "C" int hm_rvs(int dist, long n, const double* p, unsigned long long seed
 template <int D> static int rvs_inv_loop(long n, const double* p, unsigned long long seed, unsigned stream,
                                          unsigned long long offset, double* out) {
   using DD = Dist<D>;
+  if (!InvFamily<D>::ok(p)) return -2;
   const auto k = DD::derive(p);
   double lo = 0.0;
   int len = 0;
@@ -148,8 +149,10 @@ template <int D> static int rvs_inv_loop(long n, const double* p, unsigned long 
 extern "C" int hm_rvs_inv(int dist, long n, const double* p, unsigned long long seed, unsigned stream,
                           unsigned long long offset, double* out) {
   switch (dist) {
-    case M355_POISSON: return rvs_inv_loop<M355_POISSON>(n, p, seed, stream, offset, out);
-    case M355_BINOMIAL: return rvs_inv_loop<M355_BINOMIAL>(n, p, seed, stream, offset, out);
+#define HM_INV_CASE(ID) \
+  case ID: return rvs_inv_loop<ID>(n, p, seed, stream, offset, out);
+    M355_INV_LIST(HM_INV_CASE)
+#undef HM_INV_CASE
   }
   return -1;
 }

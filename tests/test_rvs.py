@@ -52,7 +52,8 @@ def host_rvs(lib, name, n, params, seed=20260313, stream=None, offset=0):
     return out
 
 
-INV_DISTS = ("poisson", "binomial")  # scalar parameters: inversion on the tabulated cdf (k_rvs_inv) where the window fits
+INV_DISTS = ("poisson", "binomial", "negativebinomial", "betabinomial", "hypergeometric", "zi_poisson", "zi_binomial",
+             "zi_negativebinomial")  # scalar parameters: inversion on the tabulated cdf (k_rvs_inv) where the window fits
 
 
 def host_rvs_inv(lib, name, n, params, seed=20260313, stream=None, offset=0):
@@ -212,6 +213,13 @@ def test_host_sampler_discrete_families_chi2(hostlib, name, params, make):
     assert np.all(x == np.floor(x))
     assert chi2_pvalue(x, d) > 1e-3
     assert moments_ok(x, d)
+    if name in INV_DISTS:  # the sampler for scalar parameters
+        xi = host_rvs_inv(hostlib, name, 1_000_000, params)
+        assert xi is not None and np.all(xi == np.floor(xi))
+        assert chi2_pvalue(xi, d) > 1e-3
+        assert moments_ok(xi, d)
+        parts = np.concatenate([host_rvs_inv(hostlib, name, m, params, offset=o) for o, m in ((0, 7), (7, 1000), (1007, 4993))])
+        assert np.array_equal(xi[:6000], parts)
 
 
 def test_host_sampler_partition_invariance(hostlib):
@@ -486,8 +494,14 @@ def test_gpu_rvs_discrete_families(gpu, hostlib, name, params, make):
     assert x.shape == (n,) and x.dtype == np.int64
     assert chi2_pvalue(x, d) > 1e-3
     assert moments_ok(x.astype(np.float64), d)
-    h = host_rvs(hostlib, name, 200_000, params)
+    h = host_rvs_scalar(hostlib, name, 200_000, params)
     assert (x[:200_000] == h).mean() > 0.9999
+    if name in INV_DISTS:  # parameters as arrays: the per-lane samplers
+        xa = m.rvs(*[np.full(400_000, p, dtype=np.float64) for p in params], size=400_000, random_state=20260313)
+        assert xa.dtype == np.int64 and chi2_pvalue(xa, d) > 1e-3
+        assert (xa[:200_000] == host_rvs(hostlib, name, 200_000, params)).mean() > 0.9999
+        for size in (1, 2, 3, 1025):
+            assert np.array_equal(m.rvs(*params, size=size, random_state=(20260313, 77)), x[77:77 + size])
     k = 77_777
     assert np.array_equal(x[:200_000], np.concatenate([m.rvs(*params, size=k, random_state=(20260313, 0)),
                                                        m.rvs(*params, size=200_000 - k, random_state=(20260313, k))]))
