@@ -250,6 +250,10 @@ int m355_logpdf_grad(int dist, int out_dtype, int64_t n, const m355_operand* x, 
  * distributions (the reference returns int64).  Parameters as in m355_elemwise (float64 arrays
  * or scalars, indexed by (i / div) % mod).  Statistically equivalent to the reference sampler
  * (KS / chi-square), not stream-equal to NumPy's PCG64.
+ * The discrete families whose cdf window fits 2048 integers (poisson, binomial, negativebinomial, betabinomial,
+ * hypergeometric, zi_*) are sampled by inversion on a tabulated cdf when EVERY parameter is a scalar operand, and by the
+ * per-lane rejection / mixture samplers when a parameter is an array: the two forms give different (equally distributed)
+ * streams for the same parameter values; within one form the split-invariance above holds.
  */
 int m355_rvs(int dist, int out_dtype, int64_t n, int nparams, const m355_operand* params, uint64_t seed,
              uint32_t stream_id, uint64_t counter_offset, void* out, void* stream);
