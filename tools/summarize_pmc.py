@@ -6,7 +6,7 @@ falls back to on gfx950; SQ_ACTIVE_INST_* / SQ_WAVE_CYCLES count quad-cycles, MI
   lane_util   = SQ_THREAD_CYCLES_VALU / (64 * SQ_ACTIVE_INST_VALU)   active lanes per VALU instruction (divergence)
   mfma_busy   = SQ_VALU_MFMA_BUSY_CYCLES / (n_simd * gui_cycles)
 with gui_cycles = GRBM_GUI_ACTIVE / 8 (rocprofv3 sums the 8 XCDs) and n_simd = 1024.
-usage: python tools/summarize_pmc.py r01"""
+usage: python tools/summarize_pmc.py r01 [pass directory name: only that pass]"""
 import collections
 import csv
 import glob
@@ -18,7 +18,8 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 N_SIMD = 1024
 out = {}
-for d in sorted(glob.glob(os.path.join(root, "gpurun_out", "pmc_*"))):
+only = sys.argv[2] if len(sys.argv) > 2 else "pmc_*"
+for d in sorted(glob.glob(os.path.join(root, "gpurun_out", only))):
     if not os.path.isdir(d):
         continue
     files = sorted(glob.glob(os.path.join(d, "*", "*_counter_collection.csv")), key=os.path.getmtime, reverse=True)  # newest pass
