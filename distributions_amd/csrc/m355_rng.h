@@ -463,11 +463,12 @@ M355_DEV double sample_binomial(RngState& st, double n, double p) {
 // same window k_dtab uses): c[i] = cdf(lo + i), evaluated once per workgroup by the exact body, and a draw is the smallest
 // i with c[i] >= u -- the family's own ppf at a uniform u (discreteweibull.py:78-79 samples that way in the reference;
 // numpy's samplers for the others are rejection methods with the same law).  A guide table makes the search O(1): g[j] is
-// the answer for u = j / 1024, and the ten bits of u that select j are the top bits of the Philox word u is made of, so
+// the answer for u = j / 4096, and the twelve bits of u that select j are the top bits of the Philox word u is made of, so
 // the search runs between two neighbouring guide entries.  64 random bits per draw: elements 2k and 2k + 1 take the two
 // halves of block (k, 0), like the normal sampler.  Resolution: u lies on a 2^-53 grid in (0, 1), so atoms beyond
 // sf < 1.1e-16 are never drawn (PTRS / BTRS stop at the same scale: their acceptance tests use the same uniforms).
-constexpr int kInvGuide = 1024;
+constexpr int kInvGuideBits = 12;
+constexpr int kInvGuide = 1 << kInvGuideBits;
 M355_HD int inv_guide(const double* c, int len, int j) {  // smallest i with c[i] >= j / kInvGuide (len - 1 if there is none)
   const double t = (double)j * (1.0 / (double)kInvGuide);
   int lo = 0, hi = len - 1;
@@ -480,17 +481,19 @@ M355_HD int inv_guide(const double* c, int len, int j) {  // smallest i with c[i
   return lo;
 }
 // g has kInvGuide + 1 entries (the last one len - 1): the answer for u in cell j lies in [g[j], g[j + 1]] -- the same index
-// in most cells, one apart where an atom's boundary crosses the cell, dozens apart only in the two cells at the ends
-// (u < 2^-10 covers the whole lower tail), hence bisection and not a scan
+// in most cells, one apart where an atom's boundary crosses the cell (one comparison decides), further apart only where
+// atoms are lighter than a cell, i.e. in the tails (the cell u < 2^-12 covers the whole lower tail): bisection there
 M355_HD int inv_index(const double* c, const unsigned short* g, unsigned hi, double u) {
-  const unsigned j = hi >> 22;
+  const unsigned j = hi >> (32 - kInvGuideBits);
   int lo = (int)g[j], up = (int)g[j + 1u];
-  while (lo < up) {
-    const int mid = (lo + up) >> 1;
-    if (c[mid] >= u) up = mid;
-    else lo = mid + 1;
+  if (up - lo > 1) {
+    while (lo + 1 < up) {  // invariant: the answer is in [lo, up]
+      const int mid = (lo + up) >> 1;
+      if (c[mid] >= u) up = mid;
+      else lo = mid + 1;
+    }
   }
-  return lo;
+  return c[lo] < u ? up : lo;  // (up == lo: c[lo] >= u, or the window ends below u -- inv_draw's exact continuation)
 }
 // u above the last tabulated value (the window ends where sf ~ 1e-40: only rounding of c[len - 1] leads here): go on
 // with the exact body
