@@ -377,6 +377,47 @@ def test_gpu_inversion_sampler(gpu, hostlib, name, params, d):
 
 
 @pytest.mark.gpu
+def test_gpu_inversion_sampler_dtypes_and_declined_parameters(gpu):
+    """k_rvs_inv through the C-ABI: float64 / float32 outputs and misaligned `out` (element-wise stores) carry the int64
+    draws; parameter sets the tabulated path declines keep their per-lane results."""
+    import ctypes
+
+    import torch
+
+    from distributions_amd import _lib, binomial, poisson, zi_poisson
+    from distributions_amd._lib import F32, F64, I64, Operand
+
+    L = _lib.lib()
+    dev = torch.device("cuda", 0)
+    n = 100_001
+
+    def raw(name, p, odt, tdt, offset=0, shift=0):
+        ops = (Operand * len(p))()
+        for j, v in enumerate(p):
+            ops[j].ptr, ops[j].scalar, ops[j].div, ops[j].mod, ops[j].dtype = None, float(v), 1, 1, F64
+        buf = torch.full((n + 2,), -7, dtype=tdt, device=dev)
+        out = buf[shift:shift + n]
+        _lib.check(L.m355_rvs(DIST[name], odt, n, len(p), ops, 99, DIST[name], offset, out.data_ptr(),
+                              torch.cuda.current_stream(dev).cuda_stream))
+        torch.cuda.synchronize()
+        assert buf[:shift].eq(-7).all() and buf[shift + n:].eq(-7).all()  # nothing written outside [0, n)
+        return out.cpu().numpy()
+
+    for name, p in (("poisson", (100.0,)), ("binomial", (1000.0, 0.3)), ("negativebinomial", (20.0, 0.05))):
+        ref = raw(name, p, I64, torch.int64)
+        assert np.array_equal(ref, raw(name, p, F64, torch.float64).astype(np.int64))
+        assert np.array_equal(ref, raw(name, p, F32, torch.float32).astype(np.int64))
+        assert np.array_equal(ref, raw(name, p, I64, torch.int64, shift=1))  # 8-byte aligned only
+        assert np.array_equal(ref[5:], raw(name, p, I64, torch.int64, offset=5)[:n - 5])
+    assert poisson.rvs(0.0, size=1000, random_state=1).max() == 0
+    assert np.array_equal(binomial.rvs(50, 1.0, size=1000, random_state=1), np.full(1000, 50))
+    assert binomial.rvs(50, 0.0, size=1000, random_state=1).max() == 0
+    assert binomial.rvs(0, 0.3, size=1000, random_state=1).max() == 0
+    assert zi_poisson.rvs(0.0, 3.0, size=1000, random_state=1).max() == 0
+    assert poisson.rvs(100.0, size=0).shape == (0,)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("name, params", [(c[0], c[1]) for c in DISC_BIG] + [("poisson", (1.0e6,))])
 def test_gpu_compaction_equals_per_lane_loop(gpu, name, params):
     """The wavefront-compacting kernel (scalar parameters whose window is too long for k_rvs_inv) and the per-lane
