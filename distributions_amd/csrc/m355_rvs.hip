@@ -44,9 +44,14 @@ constexpr int kZigBlock = M355_ZIG_BLOCK;
 constexpr int kZigBlock = 512;
 #endif
 constexpr int kZigQueue = 192;  // at most 63 waiting + 128 pushed by one trip; a test batch pushes back at most the 64 it took
-__global__ __launch_bounds__(kZigBlock) void k_rvs_normal_zig(double* __restrict__ out, long long npairs, double mu,
-                                                              double sigma, unsigned long long seed, unsigned stream,
-                                                              unsigned long long pair_offset) {
+// ARR: mu and / or sigma are arrays (any operand layout of m355_elemwise); the fast path fetches them for both halves.
+template <bool ARR>
+__global__ __launch_bounds__(kZigBlock) void k_rvs_normal_zig(double* __restrict__ out, long long npairs, const DevOperand pmu,
+                                                              const DevOperand psigma, unsigned long long seed,
+                                                              unsigned stream, unsigned long long pair_offset) {
+  const double mu = pmu.scalar, sigma = psigma.scalar;
+  const bool small = 2 * npairs <= 0xffffffffll;
+  (void)small;
   __shared__ double tab[2 * kZigLayers];
   __shared__ unsigned long long q[kZigBlock / 64][kZigQueue];  // element index relative to `out` | attempt number << 56
   for (int i = threadIdx.x; i < 2 * kZigLayers; i += kZigBlock) tab[i] = kZigTab[i];
@@ -80,8 +85,12 @@ __global__ __launch_bounds__(kZigBlock) void k_rvs_normal_zig(double* __restrict
       double x;
       bool ok = zig_fast(hi, lo, tab[2 * layer], tab[2 * layer + 1], x);
       if (!ok) ok = zig_slow(z, a, layer, x);
-      if (ok || a + 1u >= (unsigned)kMaxAttempts) out[e] = __builtin_fma(sigma, x, mu);
-      else again = true;
+      if (ok || a + 1u >= (unsigned)kMaxAttempts) {
+        if constexpr (ARR) out[e] = __builtin_fma(fetch_operand(psigma, e, small), x, fetch_operand(pmu, e, small));
+        else out[e] = __builtin_fma(sigma, x, mu);
+      } else {
+        again = true;
+      }
     }
     push(again, entry + (1ull << 56));
   };
@@ -94,11 +103,17 @@ __global__ __launch_bounds__(kZigBlock) void k_rvs_normal_zig(double* __restrict
     bool f0 = zig_fast(p.c[0], p.c[1], tab[2 * l0], tab[2 * l0 + 1], x0);
     bool f1 = zig_fast(p.c[2], p.c[3], tab[2 * l1], tab[2 * l1 + 1], x1);
     d2_t v;
-    v.x = __builtin_fma(sigma, x0, mu);
-    v.y = __builtin_fma(sigma, x1, mu);
     double* dst = out + 2 * k;
     if constexpr (decltype(tail)::value) {
       if (!act) return;  // (the last trip of one wavefront: nothing follows but the final tests, which are wave-wide again)
+    }
+    if constexpr (ARR) {
+      const unsigned long long e = 2ull * (unsigned long long)k;
+      v.x = __builtin_fma(fetch_operand(psigma, e, small), x0, fetch_operand(pmu, e, small));
+      v.y = __builtin_fma(fetch_operand(psigma, e + 1ull, small), x1, fetch_operand(pmu, e + 1ull, small));
+    } else {
+      v.x = __builtin_fma(sigma, x0, mu);
+      v.y = __builtin_fma(sigma, x1, mu);
     }
     // one queue entry per lane in the common case; a lane with both halves open (2e-4) adds the second one
 #if defined(M355_ZIG_VARIANT) && (M355_ZIG_VARIANT == 1 || M355_ZIG_VARIANT == 2)  // tools/zig_probe.hip: no queue
@@ -510,13 +525,16 @@ template <int D> int launch_rvs(const GenericOps& ops, void* out, int odt, long 
 extern "C" int m355_rvs_impl(int dist, int out_dtype, long long n, const m355::GenericOps* ops, unsigned long long seed,
                              unsigned stream_id, unsigned long long offset, void* out, hipStream_t s) {
   using namespace m355;
-  if (dist == M355_NORMAL && out_dtype == M355_F64 && ops->p[0].ptr == nullptr && ops->p[1].ptr == nullptr &&
-      (offset & 1ull) == 0 && aligned(out, 16) && n >= 2) {
+  if (dist == M355_NORMAL && out_dtype == M355_F64 && (offset & 1ull) == 0 && aligned(out, 16) && n >= 2) {
     const long long npairs = n / 2;
     const long long want = (npairs + kZigBlock - 1) / kZigBlock;
     const int blocks = (int)(want > kMaxBlocks / 2 ? kMaxBlocks / 2 : want);
-    hipLaunchKernelGGL(k_rvs_normal_zig, dim3(blocks), dim3(kZigBlock), 0, s, static_cast<double*>(out), npairs,
-                       ops->p[0].scalar, ops->p[1].scalar, seed, stream_id, offset >> 1);
+    if (ops->p[0].ptr == nullptr && ops->p[1].ptr == nullptr)
+      hipLaunchKernelGGL(k_rvs_normal_zig<false>, dim3(blocks), dim3(kZigBlock), 0, s, static_cast<double*>(out), npairs,
+                         ops->p[0], ops->p[1], seed, stream_id, offset >> 1);
+    else
+      hipLaunchKernelGGL(k_rvs_normal_zig<true>, dim3(blocks), dim3(kZigBlock), 0, s, static_cast<double*>(out), npairs,
+                         ops->p[0], ops->p[1], seed, stream_id, offset >> 1);
     int rc = (int)hipGetLastError();
     if (rc != 0 || (n & 1) == 0) return rc;
     // odd tail element

@@ -278,6 +278,17 @@ def test_gpu_normal_ziggurat_queue_equals_per_lane_loop(gpu, hostlib):
     assert np.allclose(a[:200_000], host_rvs(hostlib, "normal", 200_000, (0.5, 2.0), seed=13), rtol=1e-12, atol=0.0)
     for size in (1, 2, 63, 127, 129):
         assert np.array_equal(normal.rvs(0.5, 2.0, size=size, random_state=13), a[:size])
+    # parameters as arrays of any layout take the same kernel (k_rvs_normal_zig<true>): mu + sigma z of the standard draws
+    # (sigma a power of two: the fma rounds once, like numpy's product and sum)
+    z = normal.rvs(0.0, 1.0, size=977 * 1024, random_state=13)
+    mus = np.linspace(-3.0, 3.0, 1024)
+    cols = normal.rvs(mus[None, :], 2.0, size=(977, 1024), random_state=13)
+    assert np.array_equal(cols.reshape(-1), 2.0 * z + np.tile(mus, 977))
+    sig = np.exp2(np.arange(977) % 5 - 2.0)
+    rows = normal.rvs(0.25, sig[:, None], size=(977, 1024), random_state=13)
+    assert np.array_equal(rows.reshape(-1), np.repeat(sig, 1024) * z + 0.25)
+    odd = normal.rvs(np.tile(mus, 977)[3:], 2.0, size=977 * 1024 - 3, random_state=(13, 3))  # per-lane kernel, arrays
+    assert np.array_equal(odd, (2.0 * z + np.tile(mus, 977))[3:])
     x = normal.rvs(0.0, 1.0, size=200_000_000, random_state=14)
     assert np.isfinite(x).all() and np.abs(x).max() < 7.5
     _ziggurat_checks(x)

@@ -14,7 +14,8 @@ int main(int argc, char** argv) {
   CHECK(hipEventCreate(&e1));
   for (int rep = 0; rep < 4; ++rep) {
     CHECK(hipEventRecord(e0, 0));
-    hipLaunchKernelGGL(m355::k_rvs_normal_zig, dim3(blocks), dim3(m355::kZigBlock), 0, 0, out, npairs, 0.0, 1.0, 20260313ull, 7u, 0ull);
+    hipLaunchKernelGGL(m355::k_rvs_normal_zig<false>, dim3(blocks), dim3(m355::kZigBlock), 0, 0, out, npairs, m355::DevOperand{nullptr, 0.0, 1, 1, M355_F64},
+                       m355::DevOperand{nullptr, 1.0, 1, 1, M355_F64}, 20260313ull, 7u, 0ull);
     CHECK(hipEventRecord(e1, 0));
     CHECK(hipEventSynchronize(e1));
     float ms;
