@@ -243,8 +243,17 @@ M355_DEV MtK mt_setup(double a) {
   k.c = 1.0 / (3.0 * fsqrt(k.d));
   return k;
 }
-M355_DEV bool mt_attempt(const MtK& k, const Philox& p, double& g, double& x) {
-  x = normal_single(p);
+// WANT_Z: also the second Box-Muller output of the same block, z = r sin(angle) -- a standard normal independent of x and
+// of the acceptance uniform, hence of the accepted gamma value: Student t takes its numerator from it (one block per
+// attempt for the whole draw, no separate normal).  sin(2 pi w) is the cosine a quarter period earlier: w - 2^30.
+template <bool WANT_Z = false> M355_DEV bool mt_attempt(const MtK& k, const Philox& p, double& g, double& x, double* z = nullptr) {
+  if constexpr (WANT_Z) {
+    const double r = fsqrt(-2.0 * flog_tab(u53(p.c[0], p.c[1])));
+    x = r * cos_2pi_u32(p.c[2]);
+    *z = r * cos_2pi_u32(p.c[2] - 0x40000000u);
+  } else {
+    x = normal_single(p);
+  }
   const double u = u44(p.c[3], p.c[0]);
   const double t = 1.0 + k.c * x;
   const double vv = t * t * t;
@@ -255,7 +264,8 @@ M355_DEV bool mt_attempt(const MtK& k, const Philox& p, double& g, double& x) {
 }
 
 // Gamma(shape a, scale 1).  a == 0 -> 0; a < 0 or NaN -> NaN.  a < 1: Gamma(a + 1) U^(1/a), one more block.
-M355_DEV double sample_std_gamma(RngState& st, double a) {
+// zout: receives the accepted attempt's second normal (mt_attempt<true>); left alone for a <= 0, NaN or infinite a.
+template <bool WANT_Z = false> M355_DEV double sample_std_gamma(RngState& st, double a, double* zout = nullptr) {
   if (!(a >= 0.0)) return kNaN;
   if (a == 0.0) return 0.0;
   if (a == kInf) return kInf;
@@ -266,7 +276,7 @@ M355_DEV double sample_std_gamma(RngState& st, double a) {
     const Philox p = philox4x32_10(st.idx_lo, st.idx_hi, st.attempt, st.stream, st.k0, st.k1);
     st.attempt += 1;
     double x;
-    if (mt_attempt(k, p, g, x)) break;
+    if (mt_attempt<WANT_Z>(k, p, g, x, zout)) break;
   }
   if (boost) {
     double u1, u2;
@@ -553,11 +563,13 @@ template <int D> M355_DEV double sample_one(unsigned long long idx, unsigned lon
     const double gb = sample_std_gamma(st, p[1]);
     return ga / (ga + gb);
   } else if constexpr (D == M355_STUDENTT) {  // studentt.py:96-97: mu + sigma * z / sqrt(chi2_nu / nu)
-    const Philox b0 = philox4x32_10(st.idx_lo, st.idx_hi, 0u, st.stream, st.k0, st.k1);
-    st.attempt = 1;
-    const double z0 = normal_single(b0);
-    const double g = sample_std_gamma(st, 0.5 * p[0]);  // chi2_nu / 2
-    return p[1] + p[2] * z0 * fsqrt(0.5 * p[0] / g);
+    // the numerator is the second Box-Muller output of the accepted gamma attempt's block (mt_attempt<true>); where the
+    // gamma leg makes no attempt (nu = 0, infinite or NaN) a block of its own
+    const double a = 0.5 * p[0];
+    double z0 = 0.0;
+    if (!(a > 0.0) || a == kInf) z0 = normal_single(philox4x32_10(st.idx_lo, st.idx_hi, 0x7fffffffu, st.stream, st.k0, st.k1));
+    const double g = sample_std_gamma<true>(st, a, &z0);  // chi2_nu / 2
+    return p[1] + p[2] * z0 * fsqrt(a / g);
   } else if constexpr (D == M355_POISSON) {  // poisson.py:66-67
     return sample_poisson(st, p[0]);
   } else if constexpr (D == M355_BINOMIAL) {  // binomial.py:62-63

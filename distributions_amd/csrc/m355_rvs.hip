@@ -317,9 +317,9 @@ __global__ __launch_bounds__(kBlock) void k_rvs_compact(void* __restrict__ out, 
   }
 }
 
-// Marsaglia-Tsang samplers with the same wavefront-level compaction (scalar parameters, every gamma shape >= 1): gamma and
+// Marsaglia-Tsang samplers with the same wavefront-level compaction (scalar parameters): gamma and
 // its one-gamma relatives, beta / betascaled (two gammas: stage 0 then stage 1 with the other shape's constants -- the
-// same code), Student t (stage 0 keeps the normal of block 0, stage 1 is the gamma of shape nu / 2).  One Philox block
+// same code), Student t (one stage: the gamma of shape nu / 2, whose block also yields the numerator).  One Philox block
 // and one attempt per lane per round; a lane that finishes its element takes the next one of the chunk.  Attempt
 // numbers run on across the stages exactly as in sample_one's per-lane loops: the output is identical to k_rvs.
 template <int D> struct MtPlan;  // stages, shapes and the last step of sample_one<D>
@@ -354,7 +354,7 @@ template <> struct MtPlan<M355_BETASCALED> {
   static M355_DEV double finish(const double* p, double ga, double gb) { return ga / (ga + gb) * (p[3] - p[2]) + p[2]; }
 };
 template <> struct MtPlan<M355_STUDENTT> {
-  static constexpr int kStages = 2;  // stage 0: the normal (always accepted)
+  static constexpr int kStages = 1;  // the numerator is the accepted attempt's second normal (mt_attempt<true>)
   static M355_HD double shape(const double* p, int) { return 0.5 * p[0]; }
   static M355_DEV double finish(const double* p, double z0, double g) { return p[1] + p[2] * z0 * fsqrt(0.5 * p[0] / g); }
 };
@@ -374,8 +374,10 @@ __global__ __launch_bounds__(kBlock) void k_rvs_mt(void* __restrict__ out, int o
   const long long w1 = (wave + 1) * chunk < n ? (wave + 1) * chunk : n;
   long long next = wave * chunk;  // wave-uniform: first unassigned element
   if (next >= w1) return;
-  const MtK k0 = mt_setup(Plan::shape(pa.p, 0));
-  const MtK k1 = mt_setup(Plan::shape(pa.p, Plan::kStages - 1));
+  // a shape below 1: Gamma(a + 1) U^(1/a), the uniform from the block after the accepted attempt (sample_std_gamma)
+  const double a0 = Plan::shape(pa.p, 0), a1 = Plan::shape(pa.p, Plan::kStages - 1);
+  const MtK k0 = mt_setup(a0 < 1.0 ? a0 + 1.0 : a0);
+  const MtK k1 = mt_setup(a1 < 1.0 ? a1 + 1.0 : a1);
   long long idx = -1;  // element held by this lane (-1: none)
   unsigned attempt = 0;
   int stage = 0;
@@ -404,14 +406,16 @@ __global__ __launch_bounds__(kBlock) void k_rvs_mt(void* __restrict__ out, int o
       kk.d = stage == 0 ? k0.d : k1.d;
       kk.c = stage == 0 ? k0.c : k1.c;
       double g, x;
-      bool ok = mt_attempt(kk, ph, g, x);
-      if constexpr (D == M355_STUDENTT) {
-        if (stage == 0) {
-          ok = true;
-          g = x;
-        }
-      }
+      bool ok;
+      if constexpr (D == M355_STUDENTT) ok = mt_attempt<true>(kk, ph, g, x, &hold);
+      else ok = mt_attempt(kk, ph, g, x);
       if (ok || attempt >= (unsigned)kMaxAttempts) {
+        const double as = stage == 0 ? a0 : a1;
+        if (as < 1.0) {
+          const Philox pb = philox4x32_10((unsigned)c, (unsigned)(c >> 32), attempt, stream, (unsigned)seed, (unsigned)(seed >> 32));
+          attempt += 1;
+          g *= exp_(flog_tab(u53(pb.c[0], pb.c[1])) / as);
+        }
         if (stage + 1 < Plan::kStages) {
           hold = g;
           stage = 1;
@@ -434,7 +438,7 @@ template <int D> bool try_rvs_mt(const GenericOps& ops, void* out, int odt, long
   }
   for (int st = 0; st < MtPlan<D>::kStages; ++st) {
     const double a = MtPlan<D>::shape(pa.p, st);
-    if (!(a >= 1.0) || !(a < kInf)) return false;  // (a < 1 takes a boost block after the accepted attempt: per-lane loop)
+    if (!(a > 0.0) || !(a < kInf)) return false;
   }
   const long long want = (n + 4 * kBlock - 1) / (4 * kBlock);  // >= 256 elements per wavefront
   const int blocks = (int)(want > 8192 ? 8192 : want);

@@ -450,7 +450,9 @@ def test_gpu_compaction_equals_per_lane_loop(gpu, name, params):
 @pytest.mark.gpu
 @pytest.mark.parametrize("name, params", [("gamma", (2.5, 1.3)), ("gamma", (1.0, 2.0)), ("beta", (2.0, 5.0)),
                                           ("studentt", (5.0, 0.0, 2.0)), ("chisquared", (7.0,)), ("inversegamma", (3.0, 2.0)),
-                                          ("scaledinversechisquared", (4.0, 1.5)), ("betascaled", (2.0, 3.0, -1.0, 4.0))])
+                                          ("scaledinversechisquared", (4.0, 1.5)), ("betascaled", (2.0, 3.0, -1.0, 4.0)),
+                                          ("gamma", (0.5, 1.0)), ("beta", (0.5, 0.7)), ("beta", (0.3, 4.0)), ("studentt", (1.0, 0.0, 1.0)),
+                                          ("chisquared", (0.7,))])
 def test_gpu_marsaglia_tsang_compaction_equals_per_lane_loop(gpu, name, params):
     """k_rvs_mt (scalar parameters, shapes >= 1: one Philox block per attempt, lanes refilled as they finish) and the
     per-lane loop of k_rvs (array parameters) give bit-identical draws, for any split of the range over calls."""
