@@ -286,6 +286,51 @@ template <bool WANT_Z = false> M355_DEV double sample_std_gamma(RngState& st, do
   return g;
 }
 
+// Beta(a0, b0) with both shapes above 1: Cheng's algorithm BB (1978; R's rbeta uses it) -- ONE attempt from one Philox
+// block (two uniforms), a logistic proposal for log(X / (1 - X)) with two squeeze steps in front of the exact test;
+// expected attempts <= 4/e = 1.47 at a, b -> 1 and ~1.1 for larger shapes, where the gamma ratio of numpy's Generator
+// (the reference's sampler, beta.py:86-87) costs two Marsaglia-Tsang draws.  Shared by the per-lane loop (sample_beta_bb)
+// and the compacting kernel (k_rvs_bb).
+struct BbK {
+  double a, b, alpha, beta, gamma;  // a = min(a0, b0), b = max(a0, b0)
+  bool swapped;                     // a0 > b0: the draw is b / (b + w) instead of w / (b + w)
+};
+M355_HD bool bb_applies(double a0, double b0) { return a0 > 1.0 && b0 > 1.0 && a0 < kInf && b0 < kInf; }
+M355_DEV BbK bb_setup(double a0, double b0) {
+  BbK k;
+  k.swapped = a0 > b0;
+  k.a = k.swapped ? b0 : a0;
+  k.b = k.swapped ? a0 : b0;
+  k.alpha = k.a + k.b;
+  k.beta = fsqrt((k.alpha - 2.0) / (2.0 * k.a * k.b - k.alpha));
+  k.gamma = k.a + 1.0 / k.beta;
+  return k;
+}
+M355_DEV bool bb_attempt(const BbK& k, const Philox& p, double& x) {
+  const double u1 = u53(p.c[0], p.c[1]), u2 = u53(p.c[2], p.c[3]);
+  const double v = k.beta * flog_tab(u1 / (1.0 - u1));
+  double w = k.a * exp_(v);
+  w = w < 1.7976931348623157e308 ? w : 1.7976931348623157e308;
+  const double z = u1 * u1 * u2;
+  const double r = k.gamma * v - 1.3862943611198906;  // log 4
+  const double s = k.a + r - w;
+  x = k.swapped ? k.b / (k.b + w) : w / (k.b + w);
+  if (s + 2.6094379124341005 >= 5.0 * z) return true;  // 1 + log 5
+  const double t = flog_tab(z);
+  if (s > t) return true;
+  return r + k.alpha * flog_tab(k.alpha / (k.b + w)) >= t;
+}
+M355_DEV double sample_beta_bb(RngState& st, double a0, double b0) {
+  const BbK k = bb_setup(a0, b0);
+  double x = 0.5;
+  for (int it = 0; it < kMaxAttempts; ++it) {
+    const Philox p = philox4x32_10(st.idx_lo, st.idx_hi, st.attempt, st.stream, st.k0, st.k1);
+    st.attempt += 1;
+    if (bb_attempt(k, p, x)) break;
+  }
+  return x;
+}
+
 // log(k!) for integer-valued k >= 0: table below 16, Stirling's series above.
 M355_DEV double lfactorial(double k) {
   if (k < 16.0) {
@@ -559,6 +604,7 @@ template <int D> M355_DEV double sample_one(unsigned long long idx, unsigned lon
   } else if constexpr (D == M355_GAMMA) {  // gamma.py:61-62: shape alpha, scale 1/beta
     return sample_std_gamma(st, p[0]) / p[1];
   } else if constexpr (D == M355_BETA) {  // beta.py:86-87
+    if (bb_applies(p[0], p[1])) return sample_beta_bb(st, p[0], p[1]);
     const double ga = sample_std_gamma(st, p[0]);
     const double gb = sample_std_gamma(st, p[1]);
     return ga / (ga + gb);
@@ -706,6 +752,7 @@ template <int D> M355_DEV double sample_one(unsigned long long idx, unsigned lon
   } else if constexpr (D == M355_SCALEDINVERSECHISQUARED) {  // scaledinversechisquared.py:64-65
     return (p[0] * p[1]) / (2.0 * sample_std_gamma(st, 0.5 * p[0]));
   } else if constexpr (D == M355_BETASCALED) {  // betascaled.py:107-109
+    if (bb_applies(p[0], p[1])) return sample_beta_bb(st, p[0], p[1]) * (p[3] - p[2]) + p[2];
     const double ga = sample_std_gamma(st, p[0]);
     const double gb = sample_std_gamma(st, p[1]);
     return ga / (ga + gb) * (p[3] - p[2]) + p[2];

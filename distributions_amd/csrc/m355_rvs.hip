@@ -428,6 +428,65 @@ __global__ __launch_bounds__(kBlock) void k_rvs_mt(void* __restrict__ out, int o
   }
 }
 
+// beta / betascaled with both shapes above 1 (scalar parameters): Cheng's BB attempts (m355_rng.h) with the same lane
+// refill -- one stage, one block per attempt.  Same draws as sample_beta_bb in k_rvs.
+template <int D>
+__global__ __launch_bounds__(kBlock) void k_rvs_bb(void* __restrict__ out, int odt, long long n, const MtParams pa,
+                                                   unsigned long long seed, unsigned stream, unsigned long long offset) {
+  log_table_init();
+  const long long wave = (long long)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  const long long nwaves = (long long)gridDim.x * (kBlock / 64);
+  const long long chunk = ((n + nwaves - 1) / nwaves + 63) & ~63ll;
+  const long long w1 = (wave + 1) * chunk < n ? (wave + 1) * chunk : n;
+  long long next = wave * chunk;  // wave-uniform: first unassigned element
+  if (next >= w1) return;
+  const BbK k = bb_setup(pa.p[0], pa.p[1]);
+  long long idx = -1;  // element held by this lane (-1: none)
+  unsigned attempt = 0;
+  for (;;) {
+    const bool freed = idx < 0;
+    const unsigned long long fm = __ballot(freed);
+    const unsigned below = __builtin_amdgcn_mbcnt_hi((unsigned)(fm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)fm, 0u));
+    if (freed) {
+      const long long cand = next + below;
+      if (cand < w1) {
+        idx = cand;
+        attempt = 0;
+      }
+    }
+    next += __popcll(fm);
+    if (next > w1) next = w1;
+    const bool active = idx >= 0;
+    if (__ballot(active) == 0ull) break;  // chunk exhausted and every lane has stored its draw
+    if (active) {
+      const unsigned long long c = offset + (unsigned long long)idx;
+      const Philox ph = philox4x32_10((unsigned)c, (unsigned)(c >> 32), attempt, stream, (unsigned)seed, (unsigned)(seed >> 32));
+      attempt += 1;
+      double x;
+      if (bb_attempt(k, ph, x) || attempt >= (unsigned)kMaxAttempts) {
+        if constexpr (D == M355_BETASCALED) x = x * (pa.p[3] - pa.p[2]) + pa.p[2];
+        store_draw(out, odt, idx, x);
+        idx = -1;
+      }
+    }
+  }
+}
+template <int D> bool try_rvs_bb(const GenericOps& ops, void* out, int odt, long long n, unsigned long long seed,
+                                 unsigned stream, unsigned long long offset, hipStream_t s, int* rc) {
+  if (n < 4096) return false;
+  MtParams pa{};
+  for (int q = 0; q < Dist<D>::NP; ++q) {
+    if (ops.p[q].ptr != nullptr) return false;
+    pa.p[q] = ops.p[q].scalar;
+  }
+  if (!bb_applies(pa.p[0], pa.p[1])) return false;
+  const long long want = (n + 4 * kBlock - 1) / (4 * kBlock);  // >= 256 elements per wavefront
+  const int blocks = (int)(want > 8192 ? 8192 : want);
+  hipLaunchKernelGGL((k_rvs_bb<D>), dim3(blocks), dim3(kBlock), 0, s, out, odt, n, pa, seed, stream, offset);
+  *rc = (int)hipGetLastError();
+  return true;
+}
+
 template <int D> bool try_rvs_mt(const GenericOps& ops, void* out, int odt, long long n, unsigned long long seed,
                                  unsigned stream, unsigned long long offset, hipStream_t s, int* rc) {
   if (n < 4096) return false;
@@ -583,8 +642,14 @@ extern "C" int m355_rvs_impl(int dist, int out_dtype, long long n, const m355::G
       case M355_SCALEDINVERSECHISQUARED:
         done = try_rvs_mt<M355_SCALEDINVERSECHISQUARED>(*ops, out, out_dtype, n, seed, stream_id, offset, s, &rc);
         break;
-      case M355_BETA: done = try_rvs_mt<M355_BETA>(*ops, out, out_dtype, n, seed, stream_id, offset, s, &rc); break;
-      case M355_BETASCALED: done = try_rvs_mt<M355_BETASCALED>(*ops, out, out_dtype, n, seed, stream_id, offset, s, &rc); break;
+      case M355_BETA:
+        done = try_rvs_bb<M355_BETA>(*ops, out, out_dtype, n, seed, stream_id, offset, s, &rc) ||
+               try_rvs_mt<M355_BETA>(*ops, out, out_dtype, n, seed, stream_id, offset, s, &rc);
+        break;
+      case M355_BETASCALED:
+        done = try_rvs_bb<M355_BETASCALED>(*ops, out, out_dtype, n, seed, stream_id, offset, s, &rc) ||
+               try_rvs_mt<M355_BETASCALED>(*ops, out, out_dtype, n, seed, stream_id, offset, s, &rc);
+        break;
       case M355_STUDENTT: done = try_rvs_mt<M355_STUDENTT>(*ops, out, out_dtype, n, seed, stream_id, offset, s, &rc); break;
       default: break;
     }

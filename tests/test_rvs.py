@@ -24,6 +24,10 @@ CONT = [
     ("gamma", (50.0, 2.0), stats.gamma(50.0, scale=0.5)),
     ("beta", (2.0, 5.0), stats.beta(2, 5)),
     ("beta", (0.5, 0.7), stats.beta(0.5, 0.7)),
+    ("beta", (1.01, 1.02), stats.beta(1.01, 1.02)),           # Cheng's BB at its least efficient corner
+    ("beta", (50.0, 3.0), stats.beta(50.0, 3.0)),             # BB, shapes swapped
+    ("beta", (300.0, 700.0), stats.beta(300.0, 700.0)),
+    ("beta", (1.0, 3.0), stats.beta(1.0, 3.0)),               # a shape of exactly 1: the gamma ratio
     ("studentt", (5.0, 0.0, 2.0), stats.t(5, 0, 2)),
 ]
 DISC = [  # (comments: the per-lane sampler's branch; with scalar parameters the library inverts the tabulated cdf instead)
@@ -452,10 +456,11 @@ def test_gpu_compaction_equals_per_lane_loop(gpu, name, params):
                                           ("studentt", (5.0, 0.0, 2.0)), ("chisquared", (7.0,)), ("inversegamma", (3.0, 2.0)),
                                           ("scaledinversechisquared", (4.0, 1.5)), ("betascaled", (2.0, 3.0, -1.0, 4.0)),
                                           ("gamma", (0.5, 1.0)), ("beta", (0.5, 0.7)), ("beta", (0.3, 4.0)), ("studentt", (1.0, 0.0, 1.0)),
+                                          ("beta", (1.0, 3.0)), ("beta", (1.01, 1.02)), ("beta", (50.0, 3.0)), ("betascaled", (1.0, 0.5, -1.0, 4.0)),
                                           ("chisquared", (0.7,))])
 def test_gpu_marsaglia_tsang_compaction_equals_per_lane_loop(gpu, name, params):
-    """k_rvs_mt (scalar parameters, shapes >= 1: one Philox block per attempt, lanes refilled as they finish) and the
-    per-lane loop of k_rvs (array parameters) give bit-identical draws, for any split of the range over calls."""
+    """k_rvs_mt / k_rvs_bb (scalar parameters: one Philox block per attempt, lanes refilled as they finish) and the per-lane
+    loop of k_rvs (array parameters) give bit-identical draws, for any split of the range over calls."""
     import importlib
 
     m = importlib.import_module(f"distributions_amd.{name}")
