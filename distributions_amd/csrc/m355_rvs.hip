@@ -317,6 +317,82 @@ __global__ __launch_bounds__(kBlock) void k_rvs_compact(void* __restrict__ out, 
   }
 }
 
+// PTRS / BTRS with parameters given as ARRAYS (a Poisson regression's mu per observation): the same lane refill, every lane
+// carrying the constants of the element it holds (ptrs_setup / btrs_setup when it takes the element).  Elements the
+// rejection samplers do not serve (mu < 10, n min(p, q) < 10, degenerate or invalid parameters) are drawn on the spot by
+// sample_one's own branch and the lane takes another element next round.  The per-lane loop of k_rvs had a wavefront wait
+// for its slowest lane (~3 rounds per 64 draws at 86 % acceptance); a draw still depends only on (seed, stream, element,
+// attempt): bit-identical to k_rvs.
+template <int D>
+__global__ __launch_bounds__(kBlock) void k_rvs_compact_arr(GenericOps ops, void* __restrict__ out, int odt, long long n,
+                                                            unsigned long long seed, unsigned stream, unsigned long long offset) {
+  static_assert(D == M355_POISSON || D == M355_BINOMIAL, "PTRS / BTRS");
+  log_table_init();
+  const long long wave = (long long)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  const long long nwaves = (long long)gridDim.x * (kBlock / 64);
+  const long long chunk = ((n + nwaves - 1) / nwaves + 63) & ~63ll;
+  const long long w1 = (wave + 1) * chunk < n ? (wave + 1) * chunk : n;
+  long long next = wave * chunk;  // wave-uniform: first unassigned element
+  if (next >= w1) return;
+  const bool small = n <= 0xffffffffll;
+  PtrsK pk{};
+  BtrsK bk{};
+  long long idx = -1;  // element held by this lane (-1: none)
+  unsigned attempt = 0;
+  for (;;) {
+    const bool freed = idx < 0;
+    const unsigned long long fm = __ballot(freed);
+    const unsigned below = __builtin_amdgcn_mbcnt_hi((unsigned)(fm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)fm, 0u));
+    if (freed) {
+      const long long cand = next + below;
+      if (cand < w1) {
+        double pp[kMaxParams] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int q = 0; q < Dist<D>::NP; ++q) pp[q] = fetch_operand(ops.p[q], (unsigned long long)cand, small);
+        bool rejection;
+        if constexpr (D == M355_POISSON) {
+          rejection = pp[0] >= 10.0 && pp[0] < kInf;
+        } else {
+          const double pm = pp[1] > 0.5 ? 1.0 - pp[1] : pp[1];
+          rejection = pp[0] >= 0.0 && pp[0] < kInf && pp[1] > 0.0 && pp[1] < 1.0 && pp[0] * pm >= 10.0;
+        }
+        if (rejection) {
+          idx = cand;
+          attempt = 0;
+          if constexpr (D == M355_POISSON) pk = ptrs_setup(pp[0]);
+          else bk = btrs_setup(pp[0], pp[1]);
+        } else {
+          store_draw(out, odt, cand, sample_one<D>(offset + (unsigned long long)cand, seed, stream, pp));
+        }
+      }
+    }
+    next += __popcll(fm);
+    if (next > w1) next = w1;
+    const bool active = idx >= 0;
+    if (__ballot(active) == 0ull) {
+      if (next >= w1) break;  // chunk exhausted and every lane has stored its draw
+      continue;
+    }
+    if (active) {
+      const unsigned long long c = offset + (unsigned long long)idx;
+      const Philox ph = philox4x32_10((unsigned)c, (unsigned)(c >> 32), attempt, stream, (unsigned)seed, (unsigned)(seed >> 32));
+      attempt += 1;
+      const double u1 = u53(ph.c[0], ph.c[1]), v = u53(ph.c[2], ph.c[3]);
+      double k;
+      bool ok;
+      if constexpr (D == M355_POISSON) ok = ptrs_attempt(pk, u1, v, k);
+      else ok = btrs_attempt(bk, u1, v, k);
+      if (ok || attempt >= (unsigned)kMaxAttempts) {
+        if constexpr (D == M355_BINOMIAL) {
+          if (bk.flip) k = bk.n - k;
+        }
+        store_draw(out, odt, idx, k);
+        idx = -1;
+      }
+    }
+  }
+}
+
 // Marsaglia-Tsang samplers with the same wavefront-level compaction (scalar parameters): gamma and
 // its one-gamma relatives, beta / betascaled (two gammas: stage 0 then stage 1 with the other shape's constants -- the
 // same code), Student t (one stage: the gamma of shape nu / 2, whose block also yields the numerator).  One Philox block
@@ -621,6 +697,18 @@ extern "C" int m355_rvs_impl(int dist, int out_dtype, long long n, const m355::G
   const bool ptrs = dist == M355_POISSON && ops->p[0].ptr == nullptr && q0 >= 10.0 && q0 < kInf;
   const bool btrs = dist == M355_BINOMIAL && scalar2 && q0 >= 0.0 && q0 < kInf && q1 > 0.0 && q1 < 1.0 &&
                     q0 * (q1 > 0.5 ? 1.0 - q1 : q1) >= 10.0;
+  if ((dist == M355_POISSON || dist == M355_BINOMIAL) && n >= 4096 &&
+      (ops->p[0].ptr != nullptr || (dist == M355_BINOMIAL && ops->p[1].ptr != nullptr))) {
+    const long long want = (n + 4 * kBlock - 1) / (4 * kBlock);  // >= 256 elements per wavefront
+    const int blocks = (int)(want > 8192 ? 8192 : want);
+    if (dist == M355_POISSON)
+      hipLaunchKernelGGL((k_rvs_compact_arr<M355_POISSON>), dim3(blocks), dim3(kBlock), 0, s, *ops, out, out_dtype, n, seed,
+                         stream_id, offset);
+    else
+      hipLaunchKernelGGL((k_rvs_compact_arr<M355_BINOMIAL>), dim3(blocks), dim3(kBlock), 0, s, *ops, out, out_dtype, n, seed,
+                         stream_id, offset);
+    return (int)hipGetLastError();
+  }
   if ((ptrs || btrs) && n >= 4096) {
     const long long want = (n + 4 * kBlock - 1) / (4 * kBlock);  // >= 256 elements per wavefront
     const int blocks = (int)(want > 8192 ? 8192 : want);

@@ -452,6 +452,45 @@ def test_gpu_compaction_equals_per_lane_loop(gpu, name, params):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("name", ["poisson", "binomial"])
+def test_gpu_array_parameter_compaction(gpu, hostlib, name):
+    """k_rvs_compact_arr (PTRS / BTRS with one parameter set per element, n >= 4096) gives the draws of the per-lane loop
+    of k_rvs (calls below 4096 elements) and of the host build, for parameters that mix every branch of the samplers."""
+    import importlib
+
+    m = importlib.import_module(f"distributions_amd.{name}")
+    rng = np.random.default_rng(5)
+    n = 200_003
+    if name == "poisson":
+        mu = np.exp(rng.uniform(np.log(0.05), np.log(5e5), n))
+        mu[::97] = 0.0
+        params = (mu,)
+    else:
+        nn = np.floor(np.exp(rng.uniform(0.0, np.log(1e6), n)))
+        pr = rng.uniform(0.0, 1.0, n)
+        pr[::89] = 0.0
+        pr[1::89] = 1.0
+        nn[2::89] = 0.0
+        params = (nn, pr)
+    a = m.rvs(*params, size=n, random_state=21)
+    assert a.dtype == np.int64
+    for off in (0, 1000, 77_777, n - 1500):
+        cnt = min(1500, n - off)
+        small = m.rvs(*[p[off:off + cnt] for p in params], size=cnt, random_state=(21, off))
+        assert np.array_equal(a[off:off + cnt], small)
+    for i in range(0, 3000, 300):  # the host build, one parameter set at a time
+        h = host_rvs(hostlib, name, 1, tuple(float(p[i]) for p in params), seed=21, offset=i)
+        assert a[i] == h[0], (i, a[i], h[0])
+    # the law, at fixed parameters passed as arrays
+    fixed = (np.full(400_000, 250.0),) if name == "poisson" else (np.full(400_000, 5000.0), np.full(400_000, 0.97))
+    d = stats.poisson(250.0) if name == "poisson" else stats.binom(5000, 0.97)
+    x = m.rvs(*fixed, size=400_000, random_state=22)
+    assert chi2_pvalue(x, d) > 1e-3 and moments_ok(x.astype(np.float64), d)
+    h = host_rvs(hostlib, name, 100_000, tuple(float(p[0]) for p in fixed), seed=22)
+    assert (x[:100_000] == h).mean() > 0.9999
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("name, params", [("gamma", (2.5, 1.3)), ("gamma", (1.0, 2.0)), ("beta", (2.0, 5.0)),
                                           ("studentt", (5.0, 0.0, 2.0)), ("chisquared", (7.0,)), ("inversegamma", (3.0, 2.0)),
                                           ("scaledinversechisquared", (4.0, 1.5)), ("betascaled", (2.0, 3.0, -1.0, 4.0)),
