@@ -1,6 +1,8 @@
 // Timing variants of k_rvs_normal_zig (M355_ZIG_VARIANT, see m355_rvs.hip): 0 the library's kernel, 1 fast path only
 // (non-temporal 16-byte stores, no queue), 2 the same with plain stores, 3 full 16-byte stores plus the queue.
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -DM355_ZIG_VARIANT=N tools/zig_probe.hip -o tools/zig_probe_vN
+// other layer counts / block sizes: python tools/gen_ziggurat.py 2048 > /tmp/zigtab2048.h and
+//   -DM355_ZIGTAB_HEADER='"/tmp/zigtab2048.h"' -DM355_ZIG_BLOCK=1024
 #include "../distributions_amd/csrc/m355_rvs.hip"
 #include <cstdio>
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(e_)); return 1; } } while (0)
