@@ -104,11 +104,15 @@ __global__ __launch_bounds__(kZigBlock) void k_rvs_normal_zig(double* __restrict
     bool f1 = zig_fast(p.c[2], p.c[3], tab[2 * l1], tab[2 * l1 + 1], x1);
     d2_t v;
     double* dst = out + 2 * k;
+    bool live = true;  // (the last, partial trip: the lanes past the end neither store nor queue, but stay in the wave-wide
+                       // steps below -- `queued` must remain one value per wavefront)
     if constexpr (decltype(tail)::value) {
-      if (!act) return;  // (the last trip of one wavefront: nothing follows but the final tests, which are wave-wide again)
+      live = act;
+      f0 |= !act;
+      f1 |= !act;
     }
     if constexpr (ARR) {
-      const unsigned long long e = 2ull * (unsigned long long)k;
+      const unsigned long long e = live ? 2ull * (unsigned long long)k : 0ull;
       v.x = __builtin_fma(fetch_operand(psigma, e, small), x0, fetch_operand(pmu, e, small));
       v.y = __builtin_fma(fetch_operand(psigma, e + 1ull, small), x1, fetch_operand(pmu, e + 1ull, small));
     } else {
@@ -134,7 +138,7 @@ __global__ __launch_bounds__(kZigBlock) void k_rvs_normal_zig(double* __restrict
     return;
 #endif
     if (f0 & f1) {
-      __builtin_nontemporal_store(v, reinterpret_cast<d2_t*>(dst));
+      if (live) __builtin_nontemporal_store(v, reinterpret_cast<d2_t*>(dst));
     } else {
       if (f0) dst[0] = v.x;
       if (f1) dst[1] = v.y;

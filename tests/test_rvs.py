@@ -299,6 +299,24 @@ def test_gpu_normal_ziggurat_queue_equals_per_lane_loop(gpu, hostlib):
 
 
 @pytest.mark.gpu
+def test_gpu_normal_ziggurat_partial_last_trip(gpu):
+    """Sizes beyond the grid cap whose last trip covers ONE pair: the wavefront that takes it has entries waiting from its
+    full trips, and an open candidate of the partial trip must still reach the queue's test (the lanes past the end stay in
+    the wave-wide bookkeeping).  Against the per-lane kernel (odd offset), many seeds: the case needs an open candidate
+    in that one pair."""
+    import torch
+
+    from distributions_amd import _dispatch
+
+    n = 2 * (64 * 312_500 + 1)  # 40 000 002 draws: 131 072 wavefronts, two full trips and the partial one for wavefront 50 356
+    for seed in range(400):
+        a = _dispatch.rvs("normal", (0.0, 1.0), size=n + 1, random_state=(seed, 0), as_torch=True)
+        b = _dispatch.rvs("normal", (0.0, 1.0), size=n - 1, random_state=(seed, 1), as_torch=True)  # per-lane kernel
+        assert torch.equal(a[1:n], b), seed
+        assert torch.isfinite(a[n - 2:]).all()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("name, params, d", CONT, ids=[f"{c[0]}-{c[1]}" for c in CONT])
 def test_gpu_rvs_continuous(gpu, hostlib, name, params, d):
     import importlib
