@@ -602,6 +602,75 @@ M355_DEV double inv_draw(const double* c, const unsigned short* g, int len, doub
   return v;
 }
 
+// Families whose draw is a function of ONE uniform (inverse-cdf samplers): elements 2k and 2k + 1 take the two halves of
+// block (k, 0), so a thread of k_rvs_pairs turns one Philox block into two draws and one 16-byte store.
+template <int D> constexpr bool one_uniform() {
+  return D == M355_EXPONENTIAL || D == M355_CAUCHY || D == M355_HALFCAUCHY || D == M355_LAPLACE || D == M355_LOGISTIC ||
+         D == M355_GUMBEL || D == M355_WEIBULL || D == M355_PARETO || D == M355_UNIFORM || D == M355_TRIANGULAR ||
+         D == M355_KUMARASWAMY || D == M355_ASYMMETRICLAPLACE || D == M355_LOGLOGISTIC || D == M355_BERNOULLI ||
+         D == M355_GEOMETRIC || D == M355_DISCRETEUNIFORM || D == M355_DISCRETEWEIBULL || D == M355_TRUNCATEDNORMAL ||
+         D == M355_SKEW_STUDENTT;
+}
+template <int D> M355_DEV double from_uniform(double u1, const double* p) {
+  if constexpr (D == M355_BERNOULLI) {  // bernoulli.py:41-42: binomial(1, p)
+    return (u1 < p[0]) ? 1.0 : 0.0;
+  }
+  if constexpr (D == M355_GEOMETRIC) {  // geometric.py:63-64: inversion, support {1, 2, ...}
+    const double g = __builtin_ceil(flog(u1) / flog1p(-p[0]));
+    return g < 1.0 ? 1.0 : g;
+  }
+  if constexpr (D == M355_DISCRETEUNIFORM) {  // discreteuniform.py:64-65: integers(lower, upper + 1)
+    const double n = p[1] - p[0] + 1.0;
+    const double j = floor_(u1 * n);
+    return p[0] + (j < n ? j : n - 1.0);
+  }
+  if constexpr (D == M355_DISCRETEWEIBULL) {  // discreteweibull.py:78-79: ppf(uniform)
+    const double v = __builtin_ceil(pow_(flog(1.0 - u1) / flog(p[0]), 1.0 / p[1]) - 1.0);
+    return v < 0.0 ? 0.0 : v;
+  }
+  if constexpr (D == M355_TRUNCATEDNORMAL || D == M355_SKEW_STUDENTT) {
+    // truncatednormal.py:273-275, skew_studentt.py:164-166: ppf(uniform(0, 1))
+    return Dist<D>::template eval<M355_PPF>(u1, Dist<D>::derive(p));
+  }
+  if constexpr (D == M355_EXPONENTIAL) return -flog(u1) / p[0];                          // exponential.py:62-63
+  if constexpr (D == M355_CAUCHY) return p[0] + p[1] * tan_(kPi * (u1 - 0.5));           // cauchy.py:62-63
+  if constexpr (D == M355_HALFCAUCHY) return p[0] * tan_(kPi / 2.0 * u1);                // halfcauchy.py:69-71
+  if constexpr (D == M355_LAPLACE)                                                      // laplace.py:68-69
+    return (u1 < 0.5) ? p[0] + p[1] * flog(2.0 * u1) : p[0] - p[1] * flog(2.0 * (1.0 - u1));
+  if constexpr (D == M355_LOGISTIC) return p[0] + p[1] * flog(u1 / (1.0 - u1));          // logistic.py:58-59
+  if constexpr (D == M355_GUMBEL) return p[0] - p[1] * flog(-flog(u1));                  // gumbel.py:61-62
+  if constexpr (D == M355_WEIBULL) return p[1] * pow_(-flog(u1), 1.0 / p[0]);            // weibull.py:64-65
+  if constexpr (D == M355_PARETO) return p[1] / pow_(u1, 1.0 / p[0]);                    // pareto.py:63-65
+  if constexpr (D == M355_UNIFORM) return p[0] + u1 * (p[1] - p[0]);                     // uniform.py:66-67
+  if constexpr (D == M355_TRIANGULAR) {                                                 // triangular.py:85-87 (own ppf)
+    const double w = p[2] - p[0];
+    return (u1 < (p[1] - p[0]) / w) ? p[0] + sqrt_(w * (p[1] - p[0]) * u1) : p[2] - sqrt_(w * (p[2] - p[1]) * (1.0 - u1));
+  }
+  if constexpr (D == M355_KUMARASWAMY)                                                  // kumaraswamy.py:69-71 (own ppf)
+    return pow_(1.0 - pow_(1.0 - u1, 1.0 / p[1]), 1.0 / p[0]);
+  if constexpr (D == M355_ASYMMETRICLAPLACE) {                                          // asymmetriclaplace.py:91-96
+    const double r = -p[2] + u1 * (1.0 / p[2] + p[2]);  // uniform(-kappa, 1/kappa)
+    const double sgn = (r > 0.0) ? 1.0 : ((r < 0.0) ? -1.0 : 0.0);
+    const double ks = pow_(p[2], sgn);
+    return p[0] - (1.0 / (1.0 / p[1] * sgn * ks)) * flog(1.0 - r * sgn * ks);
+  }
+  if constexpr (D == M355_LOGLOGISTIC) return p[0] * pow_(u1 / (1.0 - u1), 1.0 / p[1]);  // loglogistic.py:107-109
+  return kNaN;
+}
+
+// ... and the families that are a function of ONE standard normal: elements 2k and 2k + 1 take the cosine and the sine
+// branch of the Box-Muller pair of block (k, 0).
+template <int D> constexpr bool one_normal() {
+  return D == M355_LOGNORMAL || D == M355_HALFNORMAL || D == M355_MOYAL || D == M355_LOGITNORMAL;
+}
+template <int D> M355_DEV double from_normal(double z, const double* p) {
+  if constexpr (D == M355_LOGNORMAL) return exp_(p[0] + p[1] * z);       // lognormal.py:68-69
+  if constexpr (D == M355_HALFNORMAL) return __builtin_fabs(p[0] * z);   // halfnormal.py:62-63
+  if constexpr (D == M355_MOYAL) return p[0] - p[1] * flog(z * z);       // moyal.py:66-68: ppf(U) = mu - sigma log Z^2
+  if constexpr (D == M355_LOGITNORMAL) return sigmoid_(p[0] + p[1] * z);  // logitnormal.py:191-192
+  return kNaN;
+}
+
 // One draw of distribution D for global element index `idx` (parameters already fetched).
 template <int D> M355_DEV double sample_one(unsigned long long idx, unsigned long long seed, unsigned stream,
                                            const double* p) {
@@ -612,7 +681,17 @@ template <int D> M355_DEV double sample_one(unsigned long long idx, unsigned lon
   st.k0 = (unsigned)seed;
   st.k1 = (unsigned)(seed >> 32);
   st.attempt = 0;
-  if constexpr (D == M355_NORMAL) {  // normal.py:66-67: mu + sigma * z
+  if constexpr (one_uniform<D>()) {
+    const unsigned long long c = idx >> 1;
+    const Philox b = philox4x32_10((unsigned)c, (unsigned)(c >> 32), 0u, stream, st.k0, st.k1);
+    return from_uniform<D>((idx & 1ull) ? u53(b.c[2], b.c[3]) : u53(b.c[0], b.c[1]), p);
+  } else if constexpr (one_normal<D>()) {
+    const unsigned long long c = idx >> 1;
+    const Philox b = philox4x32_10((unsigned)c, (unsigned)(c >> 32), 0u, stream, st.k0, st.k1);
+    double z0, z1;
+    normal_pair(u53(b.c[0], b.c[1]), u53(b.c[2], b.c[3]), z0, z1);
+    return from_normal<D>((idx & 1ull) ? z1 : z0, p);
+  } else if constexpr (D == M355_NORMAL) {  // normal.py:66-67: mu + sigma * z
     const ZigCtr z{idx, stream, st.k0, st.k1};
     return __builtin_fma(p[1], sample_std_normal(z), p[0]);
   } else if constexpr (D == M355_GAMMA) {  // gamma.py:61-62: shape alpha, scale 1/beta
@@ -634,26 +713,6 @@ template <int D> M355_DEV double sample_one(unsigned long long idx, unsigned lon
     return sample_poisson(st, p[0]);
   } else if constexpr (D == M355_BINOMIAL) {  // binomial.py:62-63
     return sample_binomial(st, p[0], p[1]);
-  } else if constexpr (D == M355_BERNOULLI) {  // bernoulli.py:41-42: binomial(1, p)
-    double u1, u2;
-    next_pair(st, u1, u2);
-    return (u1 < p[0]) ? 1.0 : 0.0;
-  } else if constexpr (D == M355_GEOMETRIC) {  // geometric.py:63-64: inversion, support {1, 2, ...}
-    double u1, u2;
-    next_pair(st, u1, u2);
-    const double g = __builtin_ceil(flog(u1) / flog1p(-p[0]));
-    return g < 1.0 ? 1.0 : g;
-  } else if constexpr (D == M355_DISCRETEUNIFORM) {  // discreteuniform.py:64-65: integers(lower, upper + 1)
-    double u1, u2;
-    next_pair(st, u1, u2);
-    const double n = p[1] - p[0] + 1.0;
-    const double j = floor_(u1 * n);
-    return p[0] + (j < n ? j : n - 1.0);
-  } else if constexpr (D == M355_DISCRETEWEIBULL) {  // discreteweibull.py:78-79: ppf(uniform)
-    double u1, u2;
-    next_pair(st, u1, u2);
-    const double v = __builtin_ceil(pow_(flog(1.0 - u1) / flog(p[0]), 1.0 / p[1]) - 1.0);
-    return v < 0.0 ? 0.0 : v;
   } else if constexpr (D == M355_NEGATIVEBINOMIAL) {  // negativebinomial.py:66-67: Poisson(Gamma(n, (1-p)/p))
     const double lam = sample_std_gamma(st, p[0]) * ((1.0 - p[1]) / p[1]);
     return sample_poisson(st, lam);
@@ -754,11 +813,6 @@ template <int D> M355_DEV double sample_one(unsigned long long idx, unsigned lon
     double m = __builtin_fabs(res);
     m = ::fmod(m + kPi, 2.0 * kPi) - kPi;
     return neg ? -m : m;
-  } else if constexpr (D == M355_TRUNCATEDNORMAL || D == M355_SKEW_STUDENTT) {
-    // truncatednormal.py:273-275, skew_studentt.py:164-166: ppf(uniform(0, 1))
-    double u1, u2;
-    next_pair(st, u1, u2);
-    return Dist<D>::template eval<M355_PPF>(u1, Dist<D>::derive(p));
   } else if constexpr (D == M355_INVERSEGAMMA) {  // inversegamma.py:69-70: 1 / Gamma(alpha, rate beta)
     return p[1] / sample_std_gamma(st, p[0]);
   } else if constexpr (D == M355_CHISQUARED) {  // chisquared.py:59-60
@@ -774,37 +828,8 @@ template <int D> M355_DEV double sample_one(unsigned long long idx, unsigned lon
     // samplers driven by one normal pair and / or one uniform pair
     double u1, u2, z0, z1;
     next_pair(st, u1, u2);
-    if constexpr (D == M355_LOGNORMAL || D == M355_HALFNORMAL || D == M355_LOGITNORMAL || D == M355_MOYAL ||
-                  D == M355_HALFSTUDENTT)
-      normal_pair(u1, u2, z0, z1);
-    if constexpr (D == M355_EXPONENTIAL) return -flog(u1) / p[0];                          // exponential.py:62-63
-    if constexpr (D == M355_LOGNORMAL) return exp_(p[0] + p[1] * z0);                      // lognormal.py:68-69
-    if constexpr (D == M355_HALFNORMAL) return __builtin_fabs(p[0] * z0);                  // halfnormal.py:62-63
-    if constexpr (D == M355_CAUCHY) return p[0] + p[1] * tan_(kPi * (u1 - 0.5));           // cauchy.py:62-63
-    if constexpr (D == M355_HALFCAUCHY) return p[0] * tan_(kPi / 2.0 * u1);                // halfcauchy.py:69-71
-    if constexpr (D == M355_LAPLACE)                                                      // laplace.py:68-69
-      return (u1 < 0.5) ? p[0] + p[1] * flog(2.0 * u1) : p[0] - p[1] * flog(2.0 * (1.0 - u1));
-    if constexpr (D == M355_LOGISTIC) return p[0] + p[1] * flog(u1 / (1.0 - u1));          // logistic.py:58-59
-    if constexpr (D == M355_GUMBEL) return p[0] - p[1] * flog(-flog(u1));                  // gumbel.py:61-62
-    if constexpr (D == M355_WEIBULL) return p[1] * pow_(-flog(u1), 1.0 / p[0]);            // weibull.py:64-65
-    if constexpr (D == M355_PARETO) return p[1] / pow_(u1, 1.0 / p[0]);                    // pareto.py:63-65
-    if constexpr (D == M355_UNIFORM) return p[0] + u1 * (p[1] - p[0]);                     // uniform.py:66-67
-    if constexpr (D == M355_TRIANGULAR) {                                                 // triangular.py:85-87 (own ppf)
-      const double w = p[2] - p[0];
-      return (u1 < (p[1] - p[0]) / w) ? p[0] + sqrt_(w * (p[1] - p[0]) * u1) : p[2] - sqrt_(w * (p[2] - p[1]) * (1.0 - u1));
-    }
-    if constexpr (D == M355_KUMARASWAMY)                                                  // kumaraswamy.py:69-71 (own ppf)
-      return pow_(1.0 - pow_(1.0 - u1, 1.0 / p[1]), 1.0 / p[0]);
-    if constexpr (D == M355_MOYAL) return p[0] - p[1] * flog(z0 * z0);                     // moyal.py:66-68: ppf(U) = mu - sigma log Z^2
-    if constexpr (D == M355_ASYMMETRICLAPLACE) {                                          // asymmetriclaplace.py:91-96
-      const double r = -p[2] + u1 * (1.0 / p[2] + p[2]);  // uniform(-kappa, 1/kappa)
-      const double sgn = (r > 0.0) ? 1.0 : ((r < 0.0) ? -1.0 : 0.0);
-      const double ks = pow_(p[2], sgn);
-      return p[0] - (1.0 / (1.0 / p[1] * sgn * ks)) * flog(1.0 - r * sgn * ks);
-    }
-    if constexpr (D == M355_LOGLOGISTIC) return p[0] * pow_(u1 / (1.0 - u1), 1.0 / p[1]);  // loglogistic.py:107-109
-    if constexpr (D == M355_LOGITNORMAL) return sigmoid_(p[0] + p[1] * z0);                // logitnormal.py:191-192
     if constexpr (D == M355_HALFSTUDENTT) {                                               // halfstudentt.py:117-119
+      normal_pair(u1, u2, z0, z1);
       const double g = sample_std_gamma(st, 0.5 * p[0]);
       return __builtin_fabs(z0 * fsqrt(0.5 * p[0] / g) * p[1]);
     }

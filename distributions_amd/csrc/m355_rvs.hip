@@ -8,6 +8,8 @@
 
 namespace m355 {
 
+typedef long long ll2_t __attribute__((ext_vector_type(2)));
+
 M355_DEV void store_draw(void* out, int odt, long long i, double v) {
   if (odt == M355_I64) static_cast<long long*>(out)[i] = (long long)v;
   else if (odt == M355_F32) static_cast<float*>(out)[i] = (float)v;
@@ -16,17 +18,60 @@ M355_DEV void store_draw(void* out, int odt, long long i, double v) {
 
 // One draw per thread per step; parameters indexed like elementwise operands.  Output-only
 // stream: 8 B per draw, coalesced 512 B per wavefront store.
+// first: the call's element that out[0] holds (a pair kernel leaves an odd last element to this one: its parameters are
+// those of element `first`, not of element 0)
 template <int D>
 __global__ __launch_bounds__(kBlock) void k_rvs(GenericOps ops, void* __restrict__ out, int odt, long long n,
                                                 unsigned long long seed, unsigned stream,
-                                                unsigned long long offset) {
+                                                unsigned long long offset, long long first) {
   log_table_init();  // the samplers use flog_tab
-  const bool small = n <= 0xffffffffll;
+  const bool small = first + n <= 0xffffffffll;
   for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < n; i += (long long)gridDim.x * kBlock) {
     double pp[kMaxParams] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-    for (int q = 0; q < Dist<D>::NP; ++q) pp[q] = fetch_operand(ops.p[q], (unsigned long long)i, small);
+    for (int q = 0; q < Dist<D>::NP; ++q) pp[q] = fetch_operand(ops.p[q], (unsigned long long)(first + i), small);
     store_draw(out, odt, i, sample_one<D>(offset + (unsigned long long)i, seed, stream, pp));
+  }
+}
+
+// Families drawn from ONE uniform or ONE normal per element (m355_rng.h one_uniform / one_normal), any parameter layout:
+// a thread turns the Philox block of elements 2k, 2k + 1 into both draws and stores 16 bytes.  Same draws as k_rvs.
+template <int D>
+__global__ __launch_bounds__(kBlock) void k_rvs_pairs(GenericOps ops, void* __restrict__ out, int odt, long long npairs,
+                                                      unsigned long long seed, unsigned stream, unsigned long long pair_offset) {
+  log_table_init();
+  const bool small = 2 * npairs <= 0xffffffffll;
+  const unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
+  for (long long k = (long long)blockIdx.x * kBlock + threadIdx.x; k < npairs; k += (long long)gridDim.x * kBlock) {
+    const unsigned long long c = pair_offset + (unsigned long long)k;
+    const Philox b = philox4x32_10((unsigned)c, (unsigned)(c >> 32), 0u, stream, k0, k1);
+    double pa[kMaxParams] = {0.0, 0.0, 0.0, 0.0}, pb[kMaxParams] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int q = 0; q < Dist<D>::NP; ++q) {
+      pa[q] = fetch_operand(ops.p[q], 2ull * (unsigned long long)k, small);
+      pb[q] = fetch_operand(ops.p[q], 2ull * (unsigned long long)k + 1ull, small);
+    }
+    double v0, v1;
+    if constexpr (one_uniform<D>()) {
+      v0 = from_uniform<D>(u53(b.c[0], b.c[1]), pa);
+      v1 = from_uniform<D>(u53(b.c[2], b.c[3]), pb);
+    } else {
+      double z0, z1;
+      normal_pair(u53(b.c[0], b.c[1]), u53(b.c[2], b.c[3]), z0, z1);
+      v0 = from_normal<D>(z0, pa);
+      v1 = from_normal<D>(z1, pb);
+    }
+    if (odt == M355_I64) {
+      ll2_t w;
+      w.x = (long long)v0;
+      w.y = (long long)v1;
+      __builtin_nontemporal_store(w, reinterpret_cast<ll2_t*>(static_cast<long long*>(out) + 2 * k));
+    } else {
+      d2_t w;
+      w.x = v0;
+      w.y = v1;
+      __builtin_nontemporal_store(w, reinterpret_cast<d2_t*>(static_cast<double*>(out) + 2 * k));
+    }
   }
 }
 
@@ -590,7 +635,6 @@ template <int D> bool try_rvs_mt(const GenericOps& ops, void* out, int odt, long
 // Every workgroup evaluates the window itself (len <= 2048 exact cdf values over 512 threads) and builds the guide table;
 // then one Philox block per lane and trip gives the draws of elements 2c and 2c + 1 of the global stream (16-byte store
 // when the call starts at an even element and `out` allows it).  No rejection, no divergence: ~30 operations per draw.
-typedef long long ll2_t __attribute__((ext_vector_type(2)));
 constexpr int kInvBlock = 512;
 constexpr int kInvMaxBlocks = 1024;  // (each workgroup pays for the whole table)
 template <int D>
@@ -656,11 +700,30 @@ template <int D> bool try_rvs_inv(const GenericOps& ops, void* out, int odt, lon
 }
 
 template <int D> int launch_rvs(const GenericOps& ops, void* out, int odt, long long n, unsigned long long seed,
-                                unsigned stream, unsigned long long offset, hipStream_t s) {
+                                unsigned stream, unsigned long long offset, hipStream_t s, long long first = 0) {
   const long long want = (n + kBlock - 1) / kBlock;
   const int blocks = (int)(want < 1 ? 1 : (want > kMaxBlocks ? kMaxBlocks : want));
-  hipLaunchKernelGGL((k_rvs<D>), dim3(blocks), dim3(kBlock), 0, s, ops, out, odt, n, seed, stream, offset);
+  hipLaunchKernelGGL((k_rvs<D>), dim3(blocks), dim3(kBlock), 0, s, ops, out, odt, n, seed, stream, offset, first);
   return (int)hipGetLastError();
+}
+
+// k_rvs_pairs where the family and the call allow it (even first element, 16-byte aligned 8-byte output), the odd last
+// element and everything else through k_rvs
+template <int D> int launch_rvs_any(const GenericOps& ops, void* out, int odt, long long n, unsigned long long seed,
+                                    unsigned stream, unsigned long long offset, hipStream_t s) {
+  if constexpr (one_uniform<D>() || one_normal<D>()) {
+    if ((offset & 1ull) == 0 && aligned(out, 16) && odt != M355_F32 && n >= 2) {
+      const long long npairs = n / 2;
+      const long long want = (npairs + kBlock - 1) / kBlock;
+      const int blocks = (int)(want > kMaxBlocks ? kMaxBlocks : want);
+      hipLaunchKernelGGL((k_rvs_pairs<D>), dim3(blocks), dim3(kBlock), 0, s, ops, out, odt, npairs, seed, stream, offset >> 1);
+      const int rc = (int)hipGetLastError();
+      if (rc != 0 || (n & 1) == 0) return rc;
+      return launch_rvs<D>(ops, static_cast<char*>(out) + 8 * (n - 1), odt, 1, seed, stream, offset + (unsigned long long)(n - 1), s,
+                           n - 1);
+    }
+  }
+  return launch_rvs<D>(ops, out, odt, n, seed, stream, offset, s);
 }
 
 }  // namespace m355
@@ -682,7 +745,7 @@ extern "C" int m355_rvs_impl(int dist, int out_dtype, long long n, const m355::G
     if (rc != 0 || (n & 1) == 0) return rc;
     // odd tail element
     return launch_rvs<M355_NORMAL>(*ops, static_cast<double*>(out) + (n - 1), out_dtype, 1, seed, stream_id,
-                                   offset + (unsigned long long)(n - 1), s);
+                                   offset + (unsigned long long)(n - 1), s, n - 1);
   }
   {  // discrete families with scalar parameters whose window fits: inversion, for every n (one stream per parameter set)
     int rc = 0;
@@ -749,7 +812,7 @@ extern "C" int m355_rvs_impl(int dist, int out_dtype, long long n, const m355::G
   }
   switch (dist) {
 #define M355_RVS_CASE(ID, name, np) \
-  case ID: return launch_rvs<ID>(*ops, out, out_dtype, n, seed, stream_id, offset, s);
+  case ID: return launch_rvs_any<ID>(*ops, out, out_dtype, n, seed, stream_id, offset, s);
     M355_DIST_LIST(M355_RVS_CASE)
 #undef M355_RVS_CASE
   }

@@ -215,7 +215,9 @@ def test_host_sampler_discrete_families_chi2(hostlib, name, params, make):
     d = make()
     x = host_rvs(hostlib, name, 400_000, params)
     assert np.all(x == np.floor(x))
-    assert chi2_pvalue(x, d) > 1e-3
+    if chi2_pvalue(x, d) <= 1e-3:  # one stream in a thousand lands here by chance: a second, larger one must not
+        x = host_rvs(hostlib, name, 4_000_000, params, seed=11)
+        assert chi2_pvalue(x, d) > 1e-2
     assert moments_ok(x, d)
     if name in INV_DISTS:  # the sampler for scalar parameters
         xi = host_rvs_inv(hostlib, name, 1_000_000, params)
@@ -291,6 +293,8 @@ def test_gpu_normal_ziggurat_queue_equals_per_lane_loop(gpu, hostlib):
     sig = np.exp2(np.arange(977) % 5 - 2.0)
     rows = normal.rvs(0.25, sig[:, None], size=(977, 1024), random_state=13)
     assert np.array_equal(rows.reshape(-1), np.repeat(sig, 1024) * z + 0.25)
+    last = normal.rvs(np.tile(mus, 977)[:-1], 2.0, size=977 * 1024 - 1, random_state=13)  # odd length: the last element
+    assert np.array_equal(last, (2.0 * z + np.tile(mus, 977))[:-1])                       # takes ITS mu (per-lane launch)
     odd = normal.rvs(np.tile(mus, 977)[3:], 2.0, size=977 * 1024 - 3, random_state=(13, 3))  # per-lane kernel, arrays
     assert np.array_equal(odd, (2.0 * z + np.tile(mus, 977))[3:])
     x = normal.rvs(0.0, 1.0, size=200_000_000, random_state=14)
@@ -585,6 +589,39 @@ def test_gpu_rvs_families(gpu, name, params, make):
     h = 77_777
     assert np.array_equal(x, np.concatenate([m.rvs(*params, size=h, random_state=(21, 0)),
                                              m.rvs(*params, size=n - h, random_state=(21, h))]))
+
+
+PAIR_FAMILIES = [
+    ("exponential", (0.27,)), ("cauchy", (0.5, 2.0)), ("halfcauchy", (1.5,)), ("laplace", (0.5, 2.0)), ("logistic", (0.5, 2.0)),
+    ("gumbel", (0.5, 2.0)), ("weibull", (1.7, 2.0)), ("pareto", (3.0, 1.5)), ("uniform", (-1.0, 3.0)), ("triangular", (0.0, 1.0, 4.0)),
+    ("kumaraswamy", (2.0, 3.0)), ("asymmetriclaplace", (0.5, 1.5, 0.7)), ("loglogistic", (2.0, 4.0)), ("bernoulli", (0.3,)),
+    ("geometric", (0.1,)), ("discreteuniform", (-2.0, 5.0)), ("discreteweibull", (0.8, 2.0)), ("truncatednormal", (2.0, 1.5, -1.0, 5.0)),
+    ("lognormal", (2.0, 0.5)), ("halfnormal", (3.5,)), ("moyal", (0.5, 2.0)), ("logitnormal", (-1.0, 1.0)),
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name, params", PAIR_FAMILIES, ids=[f[0] for f in PAIR_FAMILIES])
+def test_gpu_pairs_kernel_equals_per_lane_kernel(gpu, name, params):
+    """k_rvs_pairs (one Philox block -> the draws of elements 2k and 2k + 1, one 16-byte store; even first element) and
+    k_rvs (odd first element: one element per thread) give the same stream, with scalar parameters and with every
+    parameter an array; an odd length leaves its last element, with ITS parameters, to k_rvs."""
+    import importlib
+
+    m = importlib.import_module(f"distributions_amd.{name}")
+    n = 100_001
+    a = m.rvs(*params, size=n, random_state=(31, 0))
+    b = m.rvs(*params, size=n - 1, random_state=(31, 1))
+    assert a.shape == (n,) and np.array_equal(a[1:], b, equal_nan=True)
+    rng = np.random.default_rng(3)
+    arrs = [np.full(n, p) * (1.0 if name in ("bernoulli", "geometric", "discreteuniform", "discreteweibull", "kumaraswamy", "triangular",
+                                               "truncatednormal", "pareto") else rng.uniform(0.9, 1.1, n)) for p in params]
+    aa = m.rvs(*arrs, size=n, random_state=(31, 0))
+    bb = m.rvs(*[v[1:] for v in arrs], size=n - 1, random_state=(31, 1))
+    assert np.array_equal(aa[1:], bb, equal_nan=True)
+    if all(np.all(v == v[0]) for v in arrs):
+        assert np.array_equal(aa, a, equal_nan=True)
+    assert np.isfinite(a.astype(np.float64)).all()
 
 
 @pytest.mark.gpu
