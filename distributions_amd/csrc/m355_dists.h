@@ -323,9 +323,10 @@ template <> struct Dist<M355_BETA> {
     const double v = tab_warped(k) ? tab_unwarp(w) : w;
     const double e = exp_(-__builtin_fabs(v));
     const double sm = fdiv(e, 1.0 + e);
-    if (v < 0.0) return eval<FN>(sm, k);
+    if (v < 0.0) return eval<FN, false>(sm, k);
     constexpr bool UP = FN == M355_LOGSF || FN == M355_SF;
-    const double I = UP ? betainc_xy(k.b, k.a, sm, 1.0 - sm, k.lbeta) : betainc_xy(k.a, k.b, 1.0 - sm, sm, k.lbeta);
+    // (<false>: inside tab_ok, a + b <= 500, the continued fraction's 3e-17 a is within 1.5e-14 -- see tab_miss)
+    const double I = UP ? betainc_xy<false>(k.b, k.a, sm, 1.0 - sm, k.lbeta) : betainc_xy<false>(k.a, k.b, 1.0 - sm, sm, k.lbeta);
     return (FN == M355_LOGCDF || FN == M355_LOGSF) ? flog(I) : I;
   }
   static M355_DEV double logpdf(double x, const K& k) {
@@ -383,30 +384,33 @@ template <> struct Dist<M355_BETA> {
     return reg + s.exc;
   }
   // beta.py:90-99
-  static M355_DEV double logcdf(double x, const K& k) {
+  template <bool ASYM = true> static M355_DEV double logcdf(double x, const K& k) {
     if (x < 0.0) return -kInf;
-    if (x < 1.0) return flog(betainc_(k.a, k.b, x, k.lbeta));
+    if (x < 1.0) return flog(betainc_<ASYM>(k.a, k.b, x, k.lbeta));
     return (x == x) ? 0.0 : 0.0;  // x >= 1 and NaN (all comparisons false) both select 0
   }
   // beta.py:111-120
-  static M355_DEV double logsf(double x, const K& k) {
+  template <bool ASYM = true> static M355_DEV double logsf(double x, const K& k) {
     if (x < 0.0) return 0.0;
-    if (x < 1.0) return flog(betainc_(k.b, k.a, 1.0 - x, k.lbeta));
+    if (x < 1.0) return flog(betainc_<ASYM>(k.b, k.a, 1.0 - x, k.lbeta));
     return -kInf;
   }
-  template <int FN> static M355_DEV double eval(double x, const K& k) {
+  template <int FN, bool ASYM = true> static M355_DEV double eval(double x, const K& k) {
     if constexpr (FN == M355_LOGPDF) return logpdf(x, k);
     if constexpr (FN == M355_PDF) return exp_(logpdf(x, k));  // beta.py:74-75
-    if constexpr (FN == M355_LOGCDF) return logcdf(x, k);
-    if constexpr (FN == M355_LOGSF) return logsf(x, k);
-    if constexpr (FN == M355_CDF) return exp_(logcdf(x, k));  // beta.py:66-67
-    if constexpr (FN == M355_SF) return exp_(logsf(x, k));    // beta.py:82-83
+    if constexpr (FN == M355_LOGCDF) return logcdf<ASYM>(x, k);
+    if constexpr (FN == M355_LOGSF) return logsf<ASYM>(x, k);
+    if constexpr (FN == M355_CDF) return exp_(logcdf<ASYM>(x, k));  // beta.py:66-67
+    if constexpr (FN == M355_SF) return exp_(logsf<ASYM>(x, k));    // beta.py:82-83
     if constexpr (FN == M355_PPF || FN == M355_ISF) {         // beta.py:78-79, 70-71
       const double q = (FN == M355_ISF) ? 1.0 - x : x;
-      return ppf_bounds_cont(betaincinv_(k.a, k.b, q, k.lbeta, k.ihalf), q, 0.0, 1.0);
+      return ppf_bounds_cont(betaincinv_<ASYM>(k.a, k.b, q, k.lbeta, k.ihalf), q, 0.0, 1.0);
     }
     return kNaN;
   }
+  // the exact body inside tab_ok (a + b <= 500): without betainc's asymptotic expansion for a parameter >= 100, whose
+  // registers and scratch would otherwise set the table kernels' budget (it improves 1.5e-14 to 1e-15 there: not needed)
+  template <int FN> static M355_DEV double tab_miss(double x, const K& k) { return eval<FN, false>(x, k); }
 };
 
 // ------------------------------------------------------------------------------------- studentt
@@ -465,7 +469,7 @@ template <> struct Dist<M355_STUDENTT> {
     double z = 0.5 * (e - fdiv(1.0, e));
     if (FN == M355_LOGSF || FN == M355_SF) z = -z;
     const double d = __builtin_fma(z, z, k.nu);
-    const double f = 0.5 * betainc_xy(0.5 * k.nu, 0.5, fdiv(k.nu, d), fdiv(z * z, d), k.lbeta_h);
+    const double f = 0.5 * betainc_xy<false>(0.5 * k.nu, 0.5, fdiv(k.nu, d), fdiv(z * z, d), k.lbeta_h);  // (nu <= 50: tab_miss)
     const double l = (z < 0.0) ? flog(f) : flog1p(-f);
     return (FN == M355_CDF || FN == M355_SF) ? exp_(l) : l;
   }
@@ -478,7 +482,7 @@ template <> struct Dist<M355_STUDENTT> {
     const double e = exp_(-__builtin_fabs(w));
     const double p = fdiv(e, 1.0 + e);
     double y;
-    const double b = betaincinv_(0.5 * k.nu, 0.5, 2.0 * p, k.lbeta_h, k.ihalf_h, &y);
+    const double b = betaincinv_<false>(0.5 * k.nu, 0.5, 2.0 * p, k.lbeta_h, k.ihalf_h, &y);
     const double r = sqrt_(k.nu) * sqrt_(fdiv(y, b));
     return __builtin_fma(w < 0.0 ? -r : r, k.sigma, k.mu);
   }
@@ -517,19 +521,30 @@ template <> struct Dist<M355_STUDENTT> {
   }
   // studentt.py:100-105.  The nu > 1e5 arm is normal.CDF(z, mu, sigma) on the already
   // standardised z (mis-import studentt.py:6); reproduced as is (quirk Q1).
-  static M355_DEV double logcdf_raw(double x, double mu, const K& k) {
+  template <bool ASYM = true> static M355_DEV double logcdf_raw(double x, double mu, const K& k) {
     const double z = (x - mu) / k.sigma;
     if (k.nu > 1e5) return 0.5 * (1.0 + erf_((z - mu) / (k.sigma * kSqrt2)));
-    const double f = 0.5 * betainc_(0.5 * k.nu, 0.5, k.nu / (z * z + k.nu), k.lbeta_h);
+    const double f = 0.5 * betainc_<ASYM>(0.5 * k.nu, 0.5, k.nu / (z * z + k.nu), k.lbeta_h);
     return (z < 0.0) ? flog(f) : flog1p(-f);
   }
-  static M355_DEV double ppf(double q, const K& k) {  // studentt.py:79-89
+  // the exact body behind a table miss (m355_elemwise.h tab_exact): tab_ok has nu <= 50, so betainc's asymptotic
+  // expansion for a parameter >= 100 stays out of the table kernels' call graph (same values)
+  template <int FN> static M355_DEV double tab_miss(double x, const K& k) {
+    if constexpr (FN == M355_LOGCDF) return logcdf_raw<false>(x, k.mu, k);
+    if constexpr (FN == M355_LOGSF) return logcdf_raw<false>(-x, -k.mu, k);
+    if constexpr (FN == M355_CDF) return exp_(logcdf_raw<false>(x, k.mu, k));
+    if constexpr (FN == M355_SF) return exp_(logcdf_raw<false>(-x, -k.mu, k));
+    if constexpr (FN == M355_PPF) return ppf<false>(x, k);
+    if constexpr (FN == M355_ISF) return ppf<false>(1.0 - x, k);
+    return eval<FN>(x, k);
+  }
+  template <bool ASYM = true> static M355_DEV double ppf(double q, const K& k) {  // studentt.py:79-89
     double r;
     if (__builtin_fabs(q - 0.5) < 1e-14) {
       r = 0.0;
     } else {
       const double qq = (q < 0.5) ? 2.0 * q : 2.0 * (1.0 - q);
-      const double b = betaincinv_(0.5 * k.nu, 0.5, qq, k.lbeta_h, k.ihalf_h);
+      const double b = betaincinv_<ASYM>(0.5 * k.nu, 0.5, qq, k.lbeta_h, k.ihalf_h);
       const double t = sqrt_(k.nu) * sqrt_(1.0 / b - 1.0);
       r = (q < 0.5) ? -t : t;
     }

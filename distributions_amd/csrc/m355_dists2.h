@@ -836,7 +836,8 @@ template <> struct Dist<M355_HALFSTUDENTT> {
     const double sm = fdiv(e, 1.0 + e);
     const double u = (w < 0.0) ? sm : 1.0 - sm, xp = (w < 0.0) ? 1.0 - sm : sm;
     constexpr bool UP = FN == M355_SF || FN == M355_LOGSF;
-    const double v = UP ? betainc_xy(0.5 * k.nu, 0.5, xp, u, k.lbeta_h) : betainc_xy(0.5, 0.5 * k.nu, u, xp, k.lbeta_h);
+    // (<false>: nu <= 50 here, no asymptotic expansion in the table kernels' call graph -- see Dist<M355_STUDENTT>::tab_miss)
+    const double v = UP ? betainc_xy<false>(0.5 * k.nu, 0.5, xp, u, k.lbeta_h) : betainc_xy<false>(0.5, 0.5 * k.nu, u, xp, k.lbeta_h);
     return (FN == M355_LOGCDF || FN == M355_LOGSF) ? flog(v) : v;
   }
   template <int FN> static M355_DEV bool tab_value_miss(double r) {
@@ -854,14 +855,14 @@ template <> struct Dist<M355_HALFSTUDENTT> {
     const double e = exp_(-__builtin_fabs(w));
     const double p = fdiv(e, 1.0 + e);
     double y, b;
-    if (w < 0.0) y = betaincinv_(0.5, 0.5 * k.nu, p, k.lbeta_h, 1.0 - k.ihalf_h, &b);
-    else b = betaincinv_(0.5 * k.nu, 0.5, p, k.lbeta_h, k.ihalf_h, &y);
+    if (w < 0.0) y = betaincinv_<false>(0.5, 0.5 * k.nu, p, k.lbeta_h, 1.0 - k.ihalf_h, &b);
+    else b = betaincinv_<false>(0.5 * k.nu, 0.5, p, k.lbeta_h, k.ihalf_h, &y);
     return k.sigma * (sqrt_(k.nu) * sqrt_(fdiv(y, b)));
   }
-  static M355_DEV double cdf(double x, const K& k) {  // halfstudentt.py:76-83
+  template <bool ASYM = true> static M355_DEV double cdf(double x, const K& k) {  // halfstudentt.py:76-83
     if (k.nu > 1e5) return halfnormal_cdf(x, k.sigma);
     const double xn = x / k.sigma;
-    const double f = 0.5 * betainc_(0.5 * k.nu, 0.5, k.nu / (xn * xn + k.nu), k.lbeta_h);
+    const double f = 0.5 * betainc_<ASYM>(0.5 * k.nu, 0.5, k.nu / (xn * xn + k.nu), k.lbeta_h);
     const double c = ((xn < 0.0) ? f : 1.0 - f) * 2.0 - 1.0;
     return cdf_bounds(c, x, 0.0, kInf);
   }
@@ -870,23 +871,24 @@ template <> struct Dist<M355_HALFSTUDENTT> {
     const double xn = x / k.sigma;
     return (x < 0.0) ? -kInf : k.c - 0.5 * (k.nu + 1.0) * flog(1.0 + (xn * xn) / k.nu) ;
   }
-  template <int FN> static M355_DEV double eval(double x, const K& k) {
+  template <int FN, bool ASYM = true> static M355_DEV double eval(double x, const K& k) {
     if constexpr (FN == M355_LOGPDF) return logpdf(x, k);
     if constexpr (FN == M355_PDF) return exp_(logpdf(x, k));          // halfstudentt.py:90-91
-    if constexpr (FN == M355_CDF) return cdf(x, k);
-    if constexpr (FN == M355_SF) return 1.0 - cdf(x, k);              // halfstudentt.py:104-105
-    if constexpr (FN == M355_LOGCDF) return flog(cdf(x, k));          // halfstudentt.py:113-114
-    if constexpr (FN == M355_LOGSF) return log1mexp_(flog(cdf(x, k)));  // halfstudentt.py:134-135
+    if constexpr (FN == M355_CDF) return cdf<ASYM>(x, k);
+    if constexpr (FN == M355_SF) return 1.0 - cdf<ASYM>(x, k);              // halfstudentt.py:104-105
+    if constexpr (FN == M355_LOGCDF) return flog(cdf<ASYM>(x, k));          // halfstudentt.py:113-114
+    if constexpr (FN == M355_LOGSF) return log1mexp_(flog(cdf<ASYM>(x, k)));  // halfstudentt.py:134-135
     if constexpr (FN == M355_PPF || FN == M355_ISF) {                // halfstudentt.py:94-101, 86-87
       const double q = (FN == M355_ISF) ? 1.0 - x : x;
       const double qf = (q + 1.0) / 2.0;
       double v;
-      if (qf < 0.5) v = betaincinv_(0.5 * k.nu, 0.5, 2.0 * qf, k.lbeta_h, k.ihalf_h);
-      else v = sqrt_(k.nu / betaincinv_(0.5 * k.nu, 0.5, 2.0 - 2.0 * qf, k.lbeta_h, k.ihalf_h) - k.nu);
+      if (qf < 0.5) v = betaincinv_<ASYM>(0.5 * k.nu, 0.5, 2.0 * qf, k.lbeta_h, k.ihalf_h);
+      else v = sqrt_(k.nu / betaincinv_<ASYM>(0.5 * k.nu, 0.5, 2.0 - 2.0 * qf, k.lbeta_h, k.ihalf_h) - k.nu);
       return ppf_bounds_cont(v * k.sigma, q, 0.0, kInf);
     }
     return kNaN;
   }
+  template <int FN> static M355_DEV double tab_miss(double x, const K& k) { return eval<FN, false>(x, k); }  // (tab_ok: nu <= 50)
 };
 
 // ----------------------------------------------------------------------------------- betascaled
@@ -933,9 +935,9 @@ template <> struct Dist<M355_BETASCALED> {
     const double sm = fdiv(e, 1.0 + e);
     const double p = (w < 0.0) ? sm : 1.0 - sm, q = (w < 0.0) ? 1.0 - sm : sm;
     constexpr bool UP = FN == M355_LOGSF || FN == M355_SF;
-    const double I = UP ? betainc_xy(k.b, k.a, q, p, k.lbeta) : betainc_xy(k.a, k.b, p, q, k.lbeta);
+    const double I = UP ? betainc_xy<false>(k.b, k.a, q, p, k.lbeta) : betainc_xy<false>(k.a, k.b, p, q, k.lbeta);  // (as Dist<M355_BETA>)
     if (FN == M355_LOGCDF || FN == M355_LOGSF) return flog(I);
-    return (FN == M355_SF) ? 1.0 - betainc_xy(k.a, k.b, p, q, k.lbeta) : I;  // betascaled.py:88-89: sf = 1 - cdf
+    return (FN == M355_SF) ? 1.0 - betainc_xy<false>(k.a, k.b, p, q, k.lbeta) : I;  // betascaled.py:88-89: sf = 1 - cdf
   }
   // sum of logpdf: sum log(x - lo), sum log(hi - x) as LogProds (protocol of Dist<M355_GAMMA>::SumAcc)
   struct SumAcc {
@@ -967,28 +969,29 @@ template <> struct Dist<M355_BETASCALED> {
     if ((x < k.lo) | (x > k.hi)) return -kInf;
     return (xlogy0_l(k.a - 1.0, flog_tab(x - k.lo)) + xlogy0_l(k.b - 1.0, flog_tab(k.hi - x))) - k.c;
   }
-  static M355_DEV double logcdf(double x, const K& k) {  // betascaled.py:97-103
+  template <bool ASYM = true> static M355_DEV double logcdf(double x, const K& k) {  // betascaled.py:97-103
     if (x < k.lo) return -kInf;
     if (x > k.hi) return 0.0;
-    return flog(betainc_(k.a, k.b, (x - k.lo) / k.w, k.lbeta));
+    return flog(betainc_<ASYM>(k.a, k.b, (x - k.lo) / k.w, k.lbeta));
   }
-  template <int FN> static M355_DEV double eval(double x, const K& k) {
+  template <int FN, bool ASYM = true> static M355_DEV double eval(double x, const K& k) {
     if constexpr (FN == M355_LOGPDF) return logpdf(x, k);
     if constexpr (FN == M355_PDF) return exp_(logpdf(x, k));        // betascaled.py:79-80
-    if constexpr (FN == M355_LOGCDF) return logcdf(x, k);
-    if constexpr (FN == M355_CDF) return exp_(logcdf(x, k));        // betascaled.py:71-72
-    if constexpr (FN == M355_SF) return 1.0 - exp_(logcdf(x, k));   // betascaled.py:88-89
+    if constexpr (FN == M355_LOGCDF) return logcdf<ASYM>(x, k);
+    if constexpr (FN == M355_CDF) return exp_(logcdf<ASYM>(x, k));        // betascaled.py:71-72
+    if constexpr (FN == M355_SF) return 1.0 - exp_(logcdf<ASYM>(x, k));   // betascaled.py:88-89
     if constexpr (FN == M355_LOGSF) {                               // betascaled.py:115-121
       if (x < k.lo) return 0.0;
       if (x > k.hi) return -kInf;
-      return flog(betainc_(k.b, k.a, 1.0 - (x - k.lo) / k.w, k.lbeta));
+      return flog(betainc_<ASYM>(k.b, k.a, 1.0 - (x - k.lo) / k.w, k.lbeta));
     }
     if constexpr (FN == M355_PPF || FN == M355_ISF) {  // betascaled.py:83-85, 75-76
       const double q = (FN == M355_ISF) ? 1.0 - x : x;
-      return ppf_bounds_cont(betaincinv_(k.a, k.b, q, k.lbeta, k.ihalf) * k.w + k.lo, q, k.lo, k.hi);
+      return ppf_bounds_cont(betaincinv_<ASYM>(k.a, k.b, q, k.lbeta, k.ihalf) * k.w + k.lo, q, k.lo, k.hi);
     }
     return kNaN;
   }
+  template <int FN> static M355_DEV double tab_miss(double x, const K& k) { return eval<FN, false>(x, k); }  // (as Dist<M355_BETA>)
 };
 
 }  // namespace m355

@@ -898,6 +898,12 @@ template <class T> struct has_tab_ok_fn<T, std::void_t<decltype(T::kTabOkFn)>> :
 // lower tail, a straight line in logit q once the logarithm is taken); the lookup returns exp(table)
 template <class T, class = void> struct has_tab_ppf_log : std::false_type {};
 template <class T> struct has_tab_ppf_log<T, std::void_t<decltype(&T::tab_ppf_log)>> : std::true_type {};
+template <class T, class = void> struct has_tab_miss : std::false_type {};  // Dist<>::tab_miss<FN>: eval<FN> for parameters inside tab_ok
+template <class T> struct has_tab_miss<T, std::void_t<decltype(&T::template tab_miss<M355_LOGCDF>)>> : std::true_type {};
+template <class DD, int FN> M355_DEV double tab_miss_eval(double x, const typename DD::K& k) {
+  if constexpr (has_tab_miss<DD>::value) return DD::template tab_miss<FN>(x, k);
+  else return DD::template eval<FN>(x, k);
+}
 template <class DD, int FN> M355_DEV bool tab_log_mode(const typename DD::K& k) {
   if constexpr ((FN == M355_PPF || FN == M355_ISF) && has_tab_ppf_log<DD>::value) return DD::tab_ppf_log(k);
   else return false;
@@ -1029,26 +1035,26 @@ template <class DD, int FN> M355_DEV double tab_node_value(double w, const typen
     const double e = exp_(-__builtin_fabs(w));
     const double p = fdiv(e, 1.0 + e);  // the smaller of q, 1 - q
     if (w <= 0.0) {
-      f = DD::template eval<M355_PPF>(p, k);
+      f = tab_miss_eval<DD, M355_PPF>(p, k);
       if constexpr (has_tab_polish_lower<DD>::value) {
         // families whose LOWER quantiles are the hard direction of their inverse (inversegamma: beta / Qinv(alpha, p))
         // polish those nodes on logcdf as the upper ones are polished on logsf
         const double lp = flog(p);
 #pragma unroll 1
         for (int it = 0; it < 2; ++it) {
-          const double lc = DD::template eval<M355_LOGCDF>(f, k);
-          const double step = (lc - lp) * exp_(lc - DD::template eval<M355_LOGPDF>(f, k));
+          const double lc = tab_miss_eval<DD, M355_LOGCDF>(f, k);
+          const double step = (lc - lp) * exp_(lc - tab_miss_eval<DD, M355_LOGPDF>(f, k));
           if (step - step == 0.0) f -= step;
           if (__builtin_fabs(step) <= 1e-9 * __builtin_fabs(f)) break;
         }
       }
     } else {
-      f = DD::template eval<M355_PPF>(1.0 - p, k);
+      f = tab_miss_eval<DD, M355_PPF>(1.0 - p, k);
       const double lp = flog(p);
 #pragma unroll 1
       for (int it = 0; it < 2; ++it) {
-        const double lsf = DD::template eval<M355_LOGSF>(f, k);
-        const double step = (lsf - lp) * exp_(lsf - DD::template eval<M355_LOGPDF>(f, k));
+        const double lsf = tab_miss_eval<DD, M355_LOGSF>(f, k);
+        const double step = (lsf - lp) * exp_(lsf - tab_miss_eval<DD, M355_LOGPDF>(f, k));
         if (step - step == 0.0) f += step;
         // (Newton squares the error: a first step below 1e-9 of the root leaves < 1e-17 for the second)
         if (__builtin_fabs(step) <= 1e-9 * __builtin_fabs(f)) break;
@@ -1056,7 +1062,7 @@ template <class DD, int FN> M355_DEV double tab_node_value(double w, const typen
     }
     if (tab_log_mode<DD, FN>(k)) f = flog(f);
   } else {
-    f = DD::template eval<FN>(DD::tab_x(w, k), k);
+    f = tab_miss_eval<DD, FN>(DD::tab_x(w, k), k);  // (nodes are evaluated inside tab_ok only)
   }
   return f;
 }
@@ -1066,7 +1072,7 @@ template <class DD> M355_DEV double tab_range_end(bool upper, const typename DD:
   double tq = kTabTailQ, we = kNaN;
 #pragma unroll 1
   for (int it = 0; it < 4 && !(we - we == 0.0); ++it, tq *= 100.0)
-    we = DD::tab_w(DD::template eval<M355_PPF>(upper ? 1.0 - tq : tq, k), k);
+    we = DD::tab_w(tab_miss_eval<DD, M355_PPF>(upper ? 1.0 - tq : tq, k), k);
   if constexpr (has_tab_cap<DD>::value) {  // (still none: the outermost usable argument)
     if (!(we - we == 0.0)) we = DD::tab_w(DD::tab_cap(upper, k), k);
   }
@@ -1074,7 +1080,7 @@ template <class DD> M355_DEV double tab_range_end(bool upper, const typename DD:
 }
 
 template <int D, int FN> __device__ __noinline__ double tab_exact(double x, const typename Dist<D>::K& k) {
-  return Dist<D>::template eval<FN>(x, k);
+  return tab_miss_eval<Dist<D>, FN>(x, k);
 }
 
 // One wavefront per four cells: lane = 16 * (cell in the group) + node; lanes 14, 15 of a cell repeat node 13.
@@ -1526,7 +1532,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(min_wave
       mask &= mask - 1;
       const long long row = row0 + (long long)b * kCtRows + rloc;  // bit b = pass * kCtLoad + slot: rows row0 + 64 b + rloc
       const long long idx = row * (long long)P + col;
-      store1(out, odt, idx, DD::template eval<FN>(load1(x, xdt, (unsigned long long)idx), k));
+      store1(out, odt, idx, tab_miss_eval<DD, FN>(load1(x, xdt, (unsigned long long)idx), k));  // (a column with a table: tab_ok)
     }
   }
 }

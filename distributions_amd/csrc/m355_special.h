@@ -676,7 +676,7 @@ M355_HD_HEAVY double betainc_cf(double a, double b, double x) {
 // works from y.  Only where a device or plain host compiler sees it (hipcc's host pass has no gammainc_q; the host
 // derives I_{1/2}(a, b) only, which never comes here).
 constexpr double kBgratMinA = 100.0;  // below, the continued fraction's 3e-17 a is inside 1e-14
-#if defined(__HIP_DEVICE_COMPILE__) || !defined(__HIPCC__)
+#if (defined(__HIP_DEVICE_COMPILE__) || !defined(__HIPCC__)) && !defined(M355_NO_BGRAT)
 #define M355_HAVE_BGRAT 1
 M355_DEV_HEAVY double betainc_bgrat(double a, double b, double x, double y) {
   const double bm1 = b - 1.0;
@@ -700,9 +700,11 @@ M355_DEV_HEAVY double betainc_bgrat(double a, double b, double x, double y) {
   const double t4 = 4.0 * t * t;
   double b2n = b;
   double fact_tnp1 = 1.0;  // (2n + 1)!
+#pragma unroll 1
   for (int n = 1; n < 32; ++n) {
     fact_tnp1 *= (double)(2 * n) * (double)(2 * n + 1);
     double pn = 0.0, f = 6.0;  // f = (2m + 1)!
+#pragma unroll 1
     for (int m = 1; m < n; ++m) {
       pn += ((double)m * b - (double)n) * fdiv(p[n - m], f);
       f *= (double)(2 * m + 2) * (double)(2 * m + 3);
@@ -721,15 +723,20 @@ M355_DEV_HEAVY double betainc_bgrat(double a, double b, double x, double y) {
 #endif
 
 // Regularised incomplete beta I_x(a,b) (pt.betainc).  `y` must be 1-x; lbeta = betaln(a,b).
-M355_HD_HEAVY double betainc_xy(double a, double b, double x, double y, double lbeta) {
+// ASYM = false: a caller that knows both parameters below kBgratMinA (the table kernels' exact body for Student t,
+// nu <= 50) leaves the asymptotic expansion out of its call graph -- it is never taken there, but its registers set the
+// budget of the whole kernel (k_tab<studentt> went from five wavefronts per SIMD to four with it).
+template <bool ASYM = true> M355_HD_HEAVY double betainc_xy(double a, double b, double x, double y, double lbeta) {
   if (!(a > 0.0) || !(b > 0.0) || !(x >= 0.0) || !(x <= 1.0)) return kNaN;
   if (x == 0.0) return 0.0;
   if (y == 0.0) return 1.0;  // (x may have rounded to 1 while y is still a tiny positive number)
 #ifdef M355_HAVE_BGRAT
   // one parameter large, the other <= 1, the argument at the large parameter's end and past the reach of the power
   // series of the small one (b x <= 1): the asymptotic expansion above (and its mirror image I_x(a, b) = 1 - I_y(b, a))
-  if (a >= kBgratMinA && b <= 1.0 && y < 0.3 && a * y > 1.0) return betainc_bgrat(a, b, x, y);
-  if (b >= kBgratMinA && a <= 1.0 && x < 0.3 && b * x > 1.0) return 1.0 - betainc_bgrat(b, a, y, x);
+  if constexpr (ASYM) {
+    if (a >= kBgratMinA && b <= 1.0 && y < 0.3 && a * y > 1.0) return betainc_bgrat(a, b, x, y);
+    if (b >= kBgratMinA && a <= 1.0 && x < 0.3 && b * x > 1.0) return 1.0 - betainc_bgrat(b, a, y, x);
+  }
 #endif
   // Evaluate on the side where x is below the mean-like threshold (a+1)/(a+b+2), where both
   // expansions converge fast; the power series only while x^n dies quickly (x <= 0.35).
@@ -754,12 +761,12 @@ M355_HD_HEAVY double betainc_xy(double a, double b, double x, double y, double l
   }
   return r;
 }
-M355_DEV double betainc_(double a, double b, double x, double lbeta) {
-  return betainc_xy(a, b, x, 1.0 - x, lbeta);
+template <bool ASYM = true> M355_DEV double betainc_(double a, double b, double x, double lbeta) {
+  return betainc_xy<ASYM>(a, b, x, 1.0 - x, lbeta);
 }
 // I_{1/2}(a, b): which half of [0, 1] the root of I_x(a, b) = p lies in.  Depends on the parameters only, so
 // Dist<>::derive computes it once per launch (host) or LDS table entry and hands it to betaincinv_.
-M355_HD double betainc_half(double a, double b, double lbeta) { return betainc_xy(a, b, 0.5, 0.5, lbeta); }
+M355_HD double betainc_half(double a, double b, double lbeta) { return betainc_xy<false>(a, b, 0.5, 0.5, lbeta); }  // (x = y = 1/2: never the expansion)
 
 // Upper-tail standard normal quantile, Q(z) = pp (0 < pp <= 1/2): the rational guess plus one Newton step on
 // erfc (error ~1e-7 z), for seeds that are worth an erfc (the Student-t seed below).
@@ -817,6 +824,7 @@ M355_DEV double betaincinv_guess(double a, double b, double p, double lbeta) {
 // Inlined into its callers (not __noinline__ like the other heavy functions): a register budget can only be given to a
 // kernel, and the binned quantile kernels give one (Dist<>::kMinWaves, m355_elemwise.h).
 // y_out (optional) receives 1 - root with the relative accuracy of whichever of the two is small (the iterate itself).
+template <bool ASYM = true>
 M355_DEV double betaincinv_(double a, double b, double p, double lbeta, double ihalf = kNaN, double* y_out = nullptr) {
   if (y_out) *y_out = kNaN;
   if (!(a > 0.0) || !(b > 0.0) || !(p >= 0.0) || !(p <= 1.0)) return kNaN;
@@ -825,7 +833,7 @@ M355_DEV double betaincinv_(double a, double b, double p, double lbeta, double i
     if (y_out) *y_out = 1.0 - r;
     return r;
   }
-  const bool rep_y = p > ((ihalf == ihalf) ? ihalf : betainc_xy(a, b, 0.5, 0.5, lbeta));
+  const bool rep_y = p > ((ihalf == ihalf) ? ihalf : betainc_xy<ASYM>(a, b, 0.5, 0.5, lbeta));
   // Equation: I_x(a,b) = p for p <= 1/2, else I_y(b,a) = 1-p (exact), so that the small tail
   // keeps full relative accuracy; betainc_xy takes x and y separately, so either equation can
   // be evaluated from either iterate.
@@ -846,7 +854,7 @@ M355_DEV double betaincinv_(double a, double b, double p, double lbeta, double i
     M355_ITER_OUTER();
     const double x = rep_y ? 1.0 - t : t;
     const double y = rep_y ? t : 1.0 - t;
-    const double tail = eq_c ? betainc_xy(b, a, y, x, lbeta) : betainc_xy(a, b, x, y, lbeta);
+    const double tail = eq_c ? betainc_xy<ASYM>(b, a, y, x, lbeta) : betainc_xy<ASYM>(a, b, x, y, lbeta);
     const double g = tail - target;
     if (g == 0.0) break;
     const double f = natural ? g : -g;  // increasing in t

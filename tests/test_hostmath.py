@@ -28,9 +28,11 @@ _dp = ctypes.POINTER(ctypes.c_double)
 def hostlib():
     csrc = os.path.join(HERE, "..", "distributions_amd", "csrc")
     deps = [SRC] + [os.path.join(csrc, f) for f in ("m355_math.h", "m355_special.h", "m355_dists.h", "m355_dists2.h", "m355_dists3.h", "m355_dists4.h", "m355_grad.h",
-                                                    "m355_dist_list.h", "m355_rng.h", "m355_moments.h", "m355_hermgauss70.h", "m355_logfact128.h")]
+                                                    "m355_dist_list.h", "m355_rng.h", "m355_zigtab.h", "m355_moments.h", "m355_hermgauss70.h", "m355_logfact128.h")]
     if not os.path.exists(LIB) or any(os.path.getmtime(d) > os.path.getmtime(LIB) for d in deps):
-        subprocess.check_call(["g++", "-O2", "-mfma", "-std=c++17", "-shared", "-fPIC", "-o", LIB, SRC])
+        tmp = f"{LIB}.{os.getpid()}.tmp"  # (several xdist workers may build at once: each writes its own file, the rename is atomic)
+        subprocess.check_call(["g++", "-O2", "-mfma", "-std=c++17", "-shared", "-fPIC", "-o", tmp, SRC])
+        os.replace(tmp, LIB)
     return ctypes.CDLL(LIB)
 
 
