@@ -1663,10 +1663,15 @@ __global__ __launch_bounds__(kBlock) void k_dtab(const void* __restrict__ x, int
 template <int D> __device__ __noinline__ double dtab_cdf_exact(double v, const typename Dist<D>::K& k) { return Dist<D>::dtab_cdf(v, k); }
 template <int D> __device__ __noinline__ double dtab_pmf_exact(double v, const typename Dist<D>::K& k) { return Dist<D>::dtab_pmf(v, k); }
 
+// (512 threads, two workgroups per CU: every workgroup evaluates the whole window -- up to 2 x 2048 incomplete beta /
+// gamma functions -- so fewer, larger workgroups; the 1280 x 256 of the first version spent 0.3 of binomial(1000, 0.3)'s
+// 1.9 ms per 1e8 there once betainc's prefactor got its cancellation-free form)
+constexpr int kDtabPpfBlock = 512;
 template <int D, int FN>
-__global__ __launch_bounds__(kBlock) void k_dtab_ppf(const void* __restrict__ x, int xdt, void* __restrict__ out, int odt,
-                                                     long long n, const typename Dist<D>::K k, double lo, int len) {
+__global__ __launch_bounds__(kDtabPpfBlock) void k_dtab_ppf(const void* __restrict__ x, int xdt, void* __restrict__ out, int odt,
+                                                            long long n, const typename Dist<D>::K k, double lo, int len) {
   using DD = Dist<D>;
+  constexpr int kBlock = kDtabPpfBlock;  // (shadows the file's 256 inside this kernel)
   __shared__ double tc[kDTabMax], tp[kDTabMax];
   if constexpr (uses_log_table<DD>::value) log_table_init();
   for (int j = threadIdx.x; j < len; j += kBlock) {
@@ -2120,9 +2125,9 @@ template <int D, int FN, bool REDUCE> int launch_fn(const LaunchArgs& a) {
         double lo = 0.0;
         int len = 0;
         if (n >= tab_min_n() && !binning_disabled() && DD::dtab_range(k, lo, len)) {
-          const long long want = (n + kBlock - 1) / kBlock;
-          const int bb = (int)(want > 5 * 256 ? 5 * 256 : want);  // 32 KiB of tables: five workgroups per CU
-          hipLaunchKernelGGL((k_dtab_ppf<D, FN>), dim3(bb), dim3(kBlock), 0, a.stream, a.x.ptr, a.x.dtype, a.out, a.out_dtype,
+          const long long want = (n + kDtabPpfBlock - 1) / kDtabPpfBlock;
+          const int bb = (int)(want > 2 * 256 ? 2 * 256 : want);  // 32 KiB of tables, 16 wavefronts per CU by registers
+          hipLaunchKernelGGL((k_dtab_ppf<D, FN>), dim3(bb), dim3(kDtabPpfBlock), 0, a.stream, a.x.ptr, a.x.dtype, a.out, a.out_dtype,
                              n, k, lo, len);
           return (int)hipGetLastError();
         }

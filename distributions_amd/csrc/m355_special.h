@@ -690,7 +690,8 @@ M355_DEV_HEAVY double betainc_bgrat(double a, double b, double x, double y) {
   // Gamma(a + b) / (Gamma(a) T^b) by Stirling: (a - 1/2) log1p(b / a) + b (log(a + b) - log T) - b + S(a + b) - S(a)
   const double lr = (a - 0.5) * flog1p(fdiv(b, a)) + b * flog1p(fdiv(0.5 * (b + 1.0), t)) - b + (stirling_corr(a + b) - stirling_corr(a));
   const double prefix = h * exp_(lr);
-  double p[32];
+  constexpr int kTerms = 12;  // (at most 7 needed over the dispatch region a >= 100, y < 0.3: 2e5 random points)
+  double p[kTerms];
   p[0] = 1.0;
   double j = fdiv(gammainc_q(b, u, lgb), h);
   double sum = prefix * j;
@@ -701,7 +702,7 @@ M355_DEV_HEAVY double betainc_bgrat(double a, double b, double x, double y) {
   double b2n = b;
   double fact_tnp1 = 1.0;  // (2n + 1)!
 #pragma unroll 1
-  for (int n = 1; n < 32; ++n) {
+  for (int n = 1; n < kTerms; ++n) {
     fact_tnp1 *= (double)(2 * n) * (double)(2 * n + 1);
     double pn = 0.0, f = 6.0;  // f = (2m + 1)!
 #pragma unroll 1
@@ -726,18 +727,25 @@ M355_DEV_HEAVY double betainc_bgrat(double a, double b, double x, double y) {
 // ASYM = false: a caller that knows both parameters below kBgratMinA (the table kernels' exact body for Student t,
 // nu <= 50) leaves the asymptotic expansion out of its call graph -- it is never taken there, but its registers set the
 // budget of the whole kernel (k_tab<studentt> went from five wavefronts per SIMD to four with it).
-template <bool ASYM = true> M355_HD_HEAVY double betainc_xy(double a, double b, double x, double y, double lbeta) {
+M355_HD_HEAVY double betainc_xy_body(double a, double b, double x, double y, double lbeta);
+template <bool ASYM = true> M355_HD double betainc_xy(double a, double b, double x, double y, double lbeta) {
   if (!(a > 0.0) || !(b > 0.0) || !(x >= 0.0) || !(x <= 1.0)) return kNaN;
   if (x == 0.0) return 0.0;
   if (y == 0.0) return 1.0;  // (x may have rounded to 1 while y is still a tiny positive number)
 #ifdef M355_HAVE_BGRAT
   // one parameter large, the other <= 1, the argument at the large parameter's end and past the reach of the power
-  // series of the small one (b x <= 1): the asymptotic expansion above (and its mirror image I_x(a, b) = 1 - I_y(b, a))
+  // series of the small one (b x <= 1): the asymptotic expansion above (and its mirror image I_x(a, b) = 1 - I_y(b, a)).
+  // Decided HERE, in the inlined wrapper, so that the out-of-line body below keeps nothing alive across that call (with the
+  // dispatch inside it, the body saved a register pair in AGPRs, which every kernel reaching it then paid for: quantile
+  // kernels compiled for three wavefronts per SIMD fell to two).
   if constexpr (ASYM) {
     if (a >= kBgratMinA && b <= 1.0 && y < 0.3 && a * y > 1.0) return betainc_bgrat(a, b, x, y);
     if (b >= kBgratMinA && a <= 1.0 && x < 0.3 && b * x > 1.0) return 1.0 - betainc_bgrat(b, a, y, x);
   }
 #endif
+  return betainc_xy_body(a, b, x, y, lbeta);
+}
+M355_HD_HEAVY double betainc_xy_body(double a, double b, double x, double y, double lbeta) {
   // Evaluate on the side where x is below the mean-like threshold (a+1)/(a+b+2), where both
   // expansions converge fast; the power series only while x^n dies quickly (x <= 0.35).
   bool flip = false;
