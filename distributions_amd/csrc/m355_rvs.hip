@@ -553,6 +553,87 @@ __global__ __launch_bounds__(kBlock) void k_rvs_mt(void* __restrict__ out, int o
   }
 }
 
+// The one-stage Marsaglia-Tsang families with parameters given as ARRAYS (a gamma regression's shape and rate per
+// observation): k_rvs_mt's lane refill with the attempt constants and the parameters carried per lane, as
+// k_rvs_compact_arr does for PTRS / BTRS.  Elements whose shape is not positive and finite are drawn by sample_one's own
+// branch.  Bit-identical to the per-lane loop of k_rvs.
+template <int D>
+__global__ __launch_bounds__(kBlock) void k_rvs_mt_arr(GenericOps ops, void* __restrict__ out, int odt, long long n,
+                                                       unsigned long long seed, unsigned stream, unsigned long long offset) {
+  using Plan = MtPlan<D>;
+  static_assert(Plan::kStages == 1, "one gamma per draw");
+  log_table_init();
+  const long long wave = (long long)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  const long long nwaves = (long long)gridDim.x * (kBlock / 64);
+  const long long chunk = ((n + nwaves - 1) / nwaves + 63) & ~63ll;
+  const long long w1 = (wave + 1) * chunk < n ? (wave + 1) * chunk : n;
+  long long next = wave * chunk;  // wave-uniform: first unassigned element
+  if (next >= w1) return;
+  const bool small = n <= 0xffffffffll;
+  long long idx = -1;  // element held by this lane (-1: none)
+  unsigned attempt = 0;
+  MtK kk{};
+  double shape = 1.0, hold = 0.0;
+  double pp[kMaxParams] = {0.0, 0.0, 0.0, 0.0};
+  for (;;) {
+    const bool freed = idx < 0;
+    const unsigned long long fm = __ballot(freed);
+    const unsigned below = __builtin_amdgcn_mbcnt_hi((unsigned)(fm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)fm, 0u));
+    if (freed) {
+      const long long cand = next + below;
+      if (cand < w1) {
+#pragma unroll
+        for (int q = 0; q < Dist<D>::NP; ++q) pp[q] = fetch_operand(ops.p[q], (unsigned long long)cand, small);
+        const double a = Plan::shape(pp, 0);
+        if (a > 0.0 && a < kInf) {
+          idx = cand;
+          attempt = 0;
+          shape = a;
+          kk = mt_setup(a < 1.0 ? a + 1.0 : a);
+        } else {
+          store_draw(out, odt, cand, sample_one<D>(offset + (unsigned long long)cand, seed, stream, pp));
+        }
+      }
+    }
+    next += __popcll(fm);
+    if (next > w1) next = w1;
+    const bool active = idx >= 0;
+    if (__ballot(active) == 0ull) {
+      if (next >= w1) break;  // chunk exhausted and every lane has stored its draw
+      continue;
+    }
+    if (active) {
+      const unsigned long long c = offset + (unsigned long long)idx;
+      const Philox ph = philox4x32_10((unsigned)c, (unsigned)(c >> 32), attempt, stream, (unsigned)seed, (unsigned)(seed >> 32));
+      attempt += 1;
+      double g, x;
+      bool ok;
+      if constexpr (D == M355_STUDENTT) ok = mt_attempt<true>(kk, ph, g, x, &hold);
+      else ok = mt_attempt(kk, ph, g, x);
+      if (ok || attempt >= (unsigned)kMaxAttempts) {
+        if (shape < 1.0) {
+          const Philox pb = philox4x32_10((unsigned)c, (unsigned)(c >> 32), attempt, stream, (unsigned)seed, (unsigned)(seed >> 32));
+          g *= exp_(flog_tab(u53(pb.c[0], pb.c[1])) / shape);
+        }
+        store_draw(out, odt, idx, Plan::finish(pp, hold, g));
+        idx = -1;
+      }
+    }
+  }
+}
+template <int D> bool try_rvs_mt_arr(const GenericOps& ops, void* out, int odt, long long n, unsigned long long seed,
+                                     unsigned stream, unsigned long long offset, hipStream_t s, int* rc) {
+  if (n < 4096) return false;
+  bool any = false;
+  for (int q = 0; q < Dist<D>::NP; ++q) any |= ops.p[q].ptr != nullptr;
+  if (!any) return false;
+  const long long want = (n + 4 * kBlock - 1) / (4 * kBlock);  // >= 256 elements per wavefront
+  const int blocks = (int)(want > 8192 ? 8192 : want);
+  hipLaunchKernelGGL((k_rvs_mt_arr<D>), dim3(blocks), dim3(kBlock), 0, s, ops, out, odt, n, seed, stream, offset);
+  *rc = (int)hipGetLastError();
+  return true;
+}
+
 // beta / betascaled with both shapes above 1 (scalar parameters): Cheng's BB attempts (m355_rng.h) with the same lane
 // refill -- one stage, one block per attempt.  Same draws as sample_beta_bb in k_rvs.
 template <int D>
@@ -791,12 +872,17 @@ extern "C" int m355_rvs_impl(int dist, int out_dtype, long long n, const m355::G
     int rc = 0;
     bool done = false;
     switch (dist) {
-      case M355_GAMMA: done = try_rvs_mt<M355_GAMMA>(*ops, out, out_dtype, n, seed, stream_id, offset, s, &rc); break;
-      case M355_INVERSEGAMMA: done = try_rvs_mt<M355_INVERSEGAMMA>(*ops, out, out_dtype, n, seed, stream_id, offset, s, &rc); break;
-      case M355_CHISQUARED: done = try_rvs_mt<M355_CHISQUARED>(*ops, out, out_dtype, n, seed, stream_id, offset, s, &rc); break;
-      case M355_SCALEDINVERSECHISQUARED:
-        done = try_rvs_mt<M355_SCALEDINVERSECHISQUARED>(*ops, out, out_dtype, n, seed, stream_id, offset, s, &rc);
-        break;
+#define M355_MT1_CASE(ID)                                                                           \
+  case ID:                                                                                          \
+    done = try_rvs_mt<ID>(*ops, out, out_dtype, n, seed, stream_id, offset, s, &rc) ||              \
+           try_rvs_mt_arr<ID>(*ops, out, out_dtype, n, seed, stream_id, offset, s, &rc);            \
+    break;
+      M355_MT1_CASE(M355_GAMMA)
+      M355_MT1_CASE(M355_INVERSEGAMMA)
+      M355_MT1_CASE(M355_CHISQUARED)
+      M355_MT1_CASE(M355_SCALEDINVERSECHISQUARED)
+      M355_MT1_CASE(M355_STUDENTT)
+#undef M355_MT1_CASE
       case M355_BETA:
         done = try_rvs_bb<M355_BETA>(*ops, out, out_dtype, n, seed, stream_id, offset, s, &rc) ||
                try_rvs_mt<M355_BETA>(*ops, out, out_dtype, n, seed, stream_id, offset, s, &rc);
@@ -805,7 +891,6 @@ extern "C" int m355_rvs_impl(int dist, int out_dtype, long long n, const m355::G
         done = try_rvs_bb<M355_BETASCALED>(*ops, out, out_dtype, n, seed, stream_id, offset, s, &rc) ||
                try_rvs_mt<M355_BETASCALED>(*ops, out, out_dtype, n, seed, stream_id, offset, s, &rc);
         break;
-      case M355_STUDENTT: done = try_rvs_mt<M355_STUDENTT>(*ops, out, out_dtype, n, seed, stream_id, offset, s, &rc); break;
       default: break;
     }
     if (done) return rc;

@@ -513,6 +513,39 @@ def test_gpu_array_parameter_compaction(gpu, hostlib, name):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("name", ["gamma", "inversegamma", "chisquared", "scaledinversechisquared", "studentt"])
+def test_gpu_array_parameter_mt_compaction(gpu, hostlib, name):
+    """k_rvs_mt_arr (one Marsaglia-Tsang stage, one parameter set per element, n >= 4096) gives the draws of the per-lane
+    loop of k_rvs (calls below 4096 elements): shapes from 0.05 to 1e4 (boost below 1), a few degenerate ones."""
+    import importlib
+
+    m = importlib.import_module(f"distributions_amd.{name}")
+    rng = np.random.default_rng(6)
+    n = 150_001
+    shape = np.exp(rng.uniform(np.log(0.05), np.log(1e4), n))
+    shape[::101] = 0.0
+    shape[1::101] = np.inf
+    scale = np.exp(rng.uniform(-2.0, 2.0, n))
+    params = {"gamma": (shape, scale), "inversegamma": (shape, scale), "chisquared": (2.0 * shape,),
+              "scaledinversechisquared": (2.0 * shape, scale), "studentt": (2.0 * shape, rng.normal(size=n), scale)}[name]
+    with np.errstate(all="ignore"):
+        a = m.rvs(*params, size=n, random_state=23)
+        for off in (0, 3000, 77_777, n - 2500):
+            cnt = min(2500, n - off)
+            small = m.rvs(*[p[off:off + cnt] for p in params], size=cnt, random_state=(23, off))
+            assert np.array_equal(a[off:off + cnt], small, equal_nan=True)
+    ok = np.isfinite(shape) & (shape > 0)
+    assert np.isfinite(a[ok]).all()
+    # the law at fixed parameters passed as arrays, against the scalar-parameter kernel's sample
+    fixed = {"gamma": (2.5, 1.3), "inversegamma": (3.0, 2.0), "chisquared": (7.0,), "scaledinversechisquared": (4.0, 1.5),
+             "studentt": (5.0, 0.0, 2.0)}[name]
+    x = m.rvs(*[np.full(400_000, v) for v in fixed], size=400_000, random_state=24)
+    y = m.rvs(*fixed, size=400_000, random_state=25)
+    assert stats.ks_2samp(x, y).pvalue > 1e-3
+    assert np.array_equal(x, m.rvs(*fixed, size=400_000, random_state=24))  # (the same attempts as the scalar kernel)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("name, params", [("gamma", (2.5, 1.3)), ("gamma", (1.0, 2.0)), ("beta", (2.0, 5.0)),
                                           ("studentt", (5.0, 0.0, 2.0)), ("chisquared", (7.0,)), ("inversegamma", (3.0, 2.0)),
                                           ("scaledinversechisquared", (4.0, 1.5)), ("betascaled", (2.0, 3.0, -1.0, 4.0)),
