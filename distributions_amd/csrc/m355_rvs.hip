@@ -693,6 +693,80 @@ template <int D> bool try_rvs_bb(const GenericOps& ops, void* out, int odt, long
   return true;
 }
 
+// beta / betascaled with parameters given as ARRAYS: the BB constants are set up when a lane takes its element; an
+// element with a shape at or below 1 (or a degenerate one) is drawn on the spot by sample_one's gamma-ratio branch.
+// Bit-identical to the per-lane loop of k_rvs.
+template <int D>
+__global__ __launch_bounds__(kBlock) void k_rvs_bb_arr(GenericOps ops, void* __restrict__ out, int odt, long long n,
+                                                       unsigned long long seed, unsigned stream, unsigned long long offset) {
+  log_table_init();
+  const long long wave = (long long)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  const long long nwaves = (long long)gridDim.x * (kBlock / 64);
+  const long long chunk = ((n + nwaves - 1) / nwaves + 63) & ~63ll;
+  const long long w1 = (wave + 1) * chunk < n ? (wave + 1) * chunk : n;
+  long long next = wave * chunk;  // wave-uniform: first unassigned element
+  if (next >= w1) return;
+  const bool small = n <= 0xffffffffll;
+  long long idx = -1;  // element held by this lane (-1: none)
+  unsigned attempt = 0;
+  BbK k{};
+  double lower = 0.0, width = 1.0;
+  for (;;) {
+    const bool freed = idx < 0;
+    const unsigned long long fm = __ballot(freed);
+    const unsigned below = __builtin_amdgcn_mbcnt_hi((unsigned)(fm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)fm, 0u));
+    if (freed) {
+      const long long cand = next + below;
+      if (cand < w1) {
+        double pp[kMaxParams] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int q = 0; q < Dist<D>::NP; ++q) pp[q] = fetch_operand(ops.p[q], (unsigned long long)cand, small);
+        if (bb_applies(pp[0], pp[1])) {
+          idx = cand;
+          attempt = 0;
+          k = bb_setup(pp[0], pp[1]);
+          if constexpr (D == M355_BETASCALED) {
+            lower = pp[2];
+            width = pp[3] - pp[2];
+          }
+        } else {
+          store_draw(out, odt, cand, sample_one<D>(offset + (unsigned long long)cand, seed, stream, pp));
+        }
+      }
+    }
+    next += __popcll(fm);
+    if (next > w1) next = w1;
+    const bool active = idx >= 0;
+    if (__ballot(active) == 0ull) {
+      if (next >= w1) break;  // chunk exhausted and every lane has stored its draw
+      continue;
+    }
+    if (active) {
+      const unsigned long long c = offset + (unsigned long long)idx;
+      const Philox ph = philox4x32_10((unsigned)c, (unsigned)(c >> 32), attempt, stream, (unsigned)seed, (unsigned)(seed >> 32));
+      attempt += 1;
+      double x;
+      if (bb_attempt(k, ph, x) || attempt >= (unsigned)kMaxAttempts) {
+        if constexpr (D == M355_BETASCALED) x = x * width + lower;
+        store_draw(out, odt, idx, x);
+        idx = -1;
+      }
+    }
+  }
+}
+template <int D> bool try_rvs_bb_arr(const GenericOps& ops, void* out, int odt, long long n, unsigned long long seed,
+                                     unsigned stream, unsigned long long offset, hipStream_t s, int* rc) {
+  if (n < 4096) return false;
+  bool any = false;
+  for (int q = 0; q < Dist<D>::NP; ++q) any |= ops.p[q].ptr != nullptr;
+  if (!any) return false;
+  const long long want = (n + 4 * kBlock - 1) / (4 * kBlock);  // >= 256 elements per wavefront
+  const int blocks = (int)(want > 8192 ? 8192 : want);
+  hipLaunchKernelGGL((k_rvs_bb_arr<D>), dim3(blocks), dim3(kBlock), 0, s, ops, out, odt, n, seed, stream, offset);
+  *rc = (int)hipGetLastError();
+  return true;
+}
+
 template <int D> bool try_rvs_mt(const GenericOps& ops, void* out, int odt, long long n, unsigned long long seed,
                                  unsigned stream, unsigned long long offset, hipStream_t s, int* rc) {
   if (n < 4096) return false;
@@ -885,11 +959,13 @@ extern "C" int m355_rvs_impl(int dist, int out_dtype, long long n, const m355::G
 #undef M355_MT1_CASE
       case M355_BETA:
         done = try_rvs_bb<M355_BETA>(*ops, out, out_dtype, n, seed, stream_id, offset, s, &rc) ||
-               try_rvs_mt<M355_BETA>(*ops, out, out_dtype, n, seed, stream_id, offset, s, &rc);
+               try_rvs_mt<M355_BETA>(*ops, out, out_dtype, n, seed, stream_id, offset, s, &rc) ||
+               try_rvs_bb_arr<M355_BETA>(*ops, out, out_dtype, n, seed, stream_id, offset, s, &rc);
         break;
       case M355_BETASCALED:
         done = try_rvs_bb<M355_BETASCALED>(*ops, out, out_dtype, n, seed, stream_id, offset, s, &rc) ||
-               try_rvs_mt<M355_BETASCALED>(*ops, out, out_dtype, n, seed, stream_id, offset, s, &rc);
+               try_rvs_mt<M355_BETASCALED>(*ops, out, out_dtype, n, seed, stream_id, offset, s, &rc) ||
+               try_rvs_bb_arr<M355_BETASCALED>(*ops, out, out_dtype, n, seed, stream_id, offset, s, &rc);
         break;
       default: break;
     }

@@ -546,6 +546,38 @@ def test_gpu_array_parameter_mt_compaction(gpu, hostlib, name):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("name", ["beta", "betascaled"])
+def test_gpu_array_parameter_beta_compaction(gpu, hostlib, name):
+    """k_rvs_bb_arr (Cheng's BB with the constants per lane, n >= 4096) gives the draws of the per-lane loop of k_rvs:
+    shapes on both sides of 1 (the gamma-ratio branch is taken on the spot), a few degenerate ones."""
+    import importlib
+
+    m = importlib.import_module(f"distributions_amd.{name}")
+    rng = np.random.default_rng(8)
+    n = 150_001
+    a = np.exp(rng.uniform(np.log(0.2), np.log(500.0), n))
+    b = np.exp(rng.uniform(np.log(0.2), np.log(500.0), n))
+    a[::97] = 1.0
+    b[1::97] = np.inf
+    a[2::97] = 0.0
+    lo, hi = rng.normal(size=n), 3.0 + rng.uniform(size=n)
+    params = (a, b) if name == "beta" else (a, b, lo, hi)
+    with np.errstate(all="ignore"):
+        x = m.rvs(*params, size=n, random_state=29)
+        for off in (0, 3000, 77_777, n - 2500):
+            cnt = min(2500, n - off)
+            small = m.rvs(*[p[off:off + cnt] for p in params], size=cnt, random_state=(29, off))
+            assert np.array_equal(x[off:off + cnt], small, equal_nan=True)
+    ok = np.isfinite(b) & (a > 0)
+    assert np.isfinite(x[ok]).all()
+    fixed = (2.0, 5.0) if name == "beta" else (2.0, 5.0, -1.0, 3.0)
+    y = m.rvs(*[np.full(400_000, v) for v in fixed], size=400_000, random_state=30)
+    assert np.array_equal(y, m.rvs(*fixed, size=400_000, random_state=30))  # (the same attempts as the scalar kernel)
+    z = (y + 1.0) / 4.0 if name == "betascaled" else y
+    assert stats.kstest(z, stats.beta(2.0, 5.0).cdf).pvalue > 1e-3
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("name, params", [("gamma", (2.5, 1.3)), ("gamma", (1.0, 2.0)), ("beta", (2.0, 5.0)),
                                           ("studentt", (5.0, 0.0, 2.0)), ("chisquared", (7.0,)), ("inversegamma", (3.0, 2.0)),
                                           ("scaledinversechisquared", (4.0, 1.5)), ("betascaled", (2.0, 3.0, -1.0, 4.0)),
