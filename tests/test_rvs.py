@@ -546,6 +546,57 @@ def test_gpu_array_parameter_mt_compaction(gpu, hostlib, name):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("name", ["negativebinomial", "zi_poisson", "zi_negativebinomial", "zi_binomial", "betabinomial"])
+def test_gpu_array_parameter_count_compaction(gpu, hostlib, name):
+    """The compound count families with array parameters: k_rvs_zi_arr (zi_poisson / zi_binomial: inflation uniform, then
+    PTRS / BTRS with the lane refill, n >= 4096) gives the draws of the per-lane loop of k_rvs, and so do the families that
+    keep that loop at every n (a split-invariance check for them): base parameters on both sides of the rejection samplers'
+    limits, gamma shapes on both sides of 1, degenerate values; the law at fixed parameters against the inversion kernel."""
+    import importlib
+
+    m = importlib.import_module(f"distributions_amd.{name}")
+    rng = np.random.default_rng(12)
+    n = 150_001
+    psi = rng.uniform(size=n)
+    psi[::89] = 0.0
+    psi[1::89] = 1.0
+    shape = np.exp(rng.uniform(np.log(0.05), np.log(1e3), n))
+    shape[::101] = 0.0
+    shape[1::101] = np.inf
+    prob = rng.uniform(0.001, 1.0, n)
+    prob[::103] = 1.0
+    prob[1::103] = 0.0
+    mu = np.exp(rng.uniform(np.log(0.05), np.log(5e4), n))
+    mu[::107] = 0.0
+    trials = np.floor(np.exp(rng.uniform(0.0, np.log(1e5), n)))
+    trials[::109] = 0.0
+    al = np.exp(rng.uniform(np.log(0.2), np.log(200.0), n))
+    be = np.exp(rng.uniform(np.log(0.2), np.log(200.0), n))
+    al[::113] = 0.0
+    params = {"negativebinomial": (shape, prob), "zi_poisson": (psi, mu), "zi_negativebinomial": (psi, shape, prob),
+              "zi_binomial": (psi, trials, prob), "betabinomial": (trials, al, be)}[name]
+    with np.errstate(all="ignore"):
+        x = m.rvs(*params, size=n, random_state=31)
+        for off in (0, 3000, 77_777, n - 2500):
+            cnt = min(2500, n - off)
+            small = m.rvs(*[p[off:off + cnt] for p in params], size=cnt, random_state=(31, off))
+            assert np.array_equal(x[off:off + cnt], small, equal_nan=True)
+        # one array parameter, the others scalars
+        fixed = {"negativebinomial": (20.0, 0.05), "zi_poisson": (0.3, 40.0), "zi_negativebinomial": (0.7, 5.0, 0.04),
+                 "zi_binomial": (0.5, 400.0, 0.3), "betabinomial": (300.0, 20.0, 30.0)}[name]
+        cnt = 300_000
+        mixed = [np.full(cnt, fixed[0])] + list(fixed[1:])
+        y = m.rvs(*mixed, size=cnt, random_state=32)
+        for off in (0, 123_456):
+            small = m.rvs(mixed[0][:2000], *fixed[1:], size=2000, random_state=(32, off))
+            assert np.array_equal(y[off:off + 2000], small)
+    z = m.rvs(*fixed, size=cnt, random_state=33)  # scalar parameters: the inversion kernel, another stream
+    assert abs(y.mean() - z.mean()) < 6.0 * np.sqrt((y.var() + z.var()) / cnt)
+    assert stats.ks_2samp(y, z).pvalue > 1e-4
+    assert abs(np.mean(y == 0) - np.mean(z == 0)) < 6.0 * np.sqrt(0.5 / cnt)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("name", ["beta", "betascaled"])
 def test_gpu_array_parameter_beta_compaction(gpu, hostlib, name):
     """k_rvs_bb_arr (Cheng's BB with the constants per lane, n >= 4096) gives the draws of the per-lane loop of k_rvs:
