@@ -597,6 +597,58 @@ def test_gpu_array_parameter_count_compaction(gpu, hostlib, name):
 
 
 @pytest.mark.gpu
+def test_gpu_array_parameter_kernels_dtypes_and_lengths(gpu):
+    """The array-parameter compaction kernels through the C-ABI: float32 / int64 outputs, a misaligned `out`, lengths on both sides of the 4096-element switch from the per-lane loop -- the draws of element i do
+    not depend on any of it, and nothing is written outside [0, n)."""
+    import ctypes
+
+    import torch
+
+    from distributions_amd import _lib
+    from distributions_amd._lib import F32, F64, I64, Operand
+
+    L = _lib.lib()
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev)
+    g.manual_seed(5)
+    u = torch.rand(20_000, dtype=torch.float64, device=dev, generator=g)
+
+    def raw(name, p, n, odt, tdt, shift=0, pdt=torch.float64):
+        ops = (Operand * len(p))()
+        keep = []
+        for j, v in enumerate(p):
+            if torch.is_tensor(v):
+                t = v[:n].to(pdt).contiguous()
+                keep.append(t)
+                ops[j].ptr, ops[j].scalar, ops[j].div, ops[j].mod, ops[j].dtype = t.data_ptr(), 0.0, 1, n, F64 if pdt == torch.float64 else F32
+            else:
+                ops[j].ptr, ops[j].scalar, ops[j].div, ops[j].mod, ops[j].dtype = None, float(v), 1, 1, F64
+        buf = torch.full((n + 2,), -7, dtype=tdt, device=dev)
+        out = buf[shift:shift + n]
+        _lib.check(L.m355_rvs(DIST[name], odt, n, len(p), ops, 77, DIST[name], 0, out.data_ptr(),
+                              torch.cuda.current_stream(dev).cuda_stream))
+        torch.cuda.synchronize()
+        assert buf[:shift].eq(-7).all() and buf[shift + n:].eq(-7).all()
+        return out.cpu().numpy()
+
+    f32 = lambda t: t.to(torch.float32).to(torch.float64)  # parameters exactly representable in float32
+    cases = (("gamma", (f32(0.3 + 30.0 * u), 1.5), False), ("studentt", (f32(1.0 + 20.0 * u), 0.0, 2.0), False),
+             ("beta", (f32(0.5 + 6.0 * u), 3.0), False), ("poisson", (f32(2.0 + 400.0 * u),), True),
+             ("binomial", (1000.0, f32(u)), True), ("zi_poisson", (0.4, f32(2.0 + 400.0 * u)), True),
+             ("zi_binomial", (f32(u), 800.0, 0.3), True))
+    for name, p, discrete in cases:
+        ref = raw(name, p, 20_000, F64, torch.float64)
+        for n in (4095, 4096, 4097, 12_345):
+            assert np.array_equal(ref[:n], raw(name, p, n, F64, torch.float64)), (name, n)
+        with pytest.raises(_lib.M355Error, match="dtype"):  # parameter arrays are float64 (include/m355_dist.h)
+            raw(name, p, 20_000, F64, torch.float64, pdt=torch.float32)
+        assert np.array_equal(ref, raw(name, p, 20_000, F64, torch.float64, shift=1)), name
+        assert np.array_equal(ref.astype(np.float32), raw(name, p, 20_000, F32, torch.float32)), name
+        if discrete:
+            assert np.array_equal(ref.astype(np.int64), raw(name, p, 20_000, I64, torch.int64)), name
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("name", ["beta", "betascaled"])
 def test_gpu_array_parameter_beta_compaction(gpu, hostlib, name):
     """k_rvs_bb_arr (Cheng's BB with the constants per lane, n >= 4096) gives the draws of the per-lane loop of k_rvs:
