@@ -616,7 +616,7 @@ template <int D> M355_DEV double from_uniform(double u1, const double* p) {
     return (u1 < p[0]) ? 1.0 : 0.0;
   }
   if constexpr (D == M355_GEOMETRIC) {  // geometric.py:63-64: inversion, support {1, 2, ...}
-    const double g = __builtin_ceil(flog(u1) / flog1p(-p[0]));
+    const double g = __builtin_ceil(flog_tab(u1) / flog1p(-p[0]));
     return g < 1.0 ? 1.0 : g;
   }
   if constexpr (D == M355_DISCRETEUNIFORM) {  // discreteuniform.py:64-65: integers(lower, upper + 1)
@@ -632,15 +632,15 @@ template <int D> M355_DEV double from_uniform(double u1, const double* p) {
     // truncatednormal.py:273-275, skew_studentt.py:164-166: ppf(uniform(0, 1))
     return Dist<D>::template eval<M355_PPF>(u1, Dist<D>::derive(p));
   }
-  if constexpr (D == M355_EXPONENTIAL) return -flog(u1) / p[0];                          // exponential.py:62-63
+  if constexpr (D == M355_EXPONENTIAL) return -flog_tab(u1) / p[0];  // exponential.py:62-63
   if constexpr (D == M355_CAUCHY) return p[0] + p[1] * tan_(kPi * (u1 - 0.5));           // cauchy.py:62-63
   if constexpr (D == M355_HALFCAUCHY) return p[0] * tan_(kPi / 2.0 * u1);                // halfcauchy.py:69-71
   if constexpr (D == M355_LAPLACE)                                                      // laplace.py:68-69
-    return (u1 < 0.5) ? p[0] + p[1] * flog(2.0 * u1) : p[0] - p[1] * flog(2.0 * (1.0 - u1));
-  if constexpr (D == M355_LOGISTIC) return p[0] + p[1] * flog(u1 / (1.0 - u1));          // logistic.py:58-59
-  if constexpr (D == M355_GUMBEL) return p[0] - p[1] * flog(-flog(u1));                  // gumbel.py:61-62
-  if constexpr (D == M355_WEIBULL) return p[1] * pow_(-flog(u1), 1.0 / p[0]);            // weibull.py:64-65
-  if constexpr (D == M355_PARETO) return p[1] / pow_(u1, 1.0 / p[0]);                    // pareto.py:63-65
+    return (u1 < 0.5) ? p[0] + p[1] * flog_tab(2.0 * u1) : p[0] - p[1] * flog_tab(2.0 * (1.0 - u1));
+  if constexpr (D == M355_LOGISTIC) return p[0] + p[1] * flog_tab(u1 / (1.0 - u1));  // logistic.py:58-59
+  if constexpr (D == M355_GUMBEL) return p[0] - p[1] * flog_tab(-flog_tab(u1));  // gumbel.py:61-62
+  if constexpr (D == M355_WEIBULL) return p[1] * exp_(flog_tab(-flog_tab(u1)) / p[0]);  // weibull.py:64-65
+  if constexpr (D == M355_PARETO) return p[1] * exp_(-flog_tab(u1) / p[0]);                    // pareto.py:63-65
   if constexpr (D == M355_UNIFORM) return p[0] + u1 * (p[1] - p[0]);                     // uniform.py:66-67
   if constexpr (D == M355_TRIANGULAR) {                                                 // triangular.py:85-87 (own ppf)
     const double w = p[2] - p[0];
@@ -654,7 +654,7 @@ template <int D> M355_DEV double from_uniform(double u1, const double* p) {
     const double ks = pow_(p[2], sgn);
     return p[0] - (1.0 / (1.0 / p[1] * sgn * ks)) * flog(1.0 - r * sgn * ks);
   }
-  if constexpr (D == M355_LOGLOGISTIC) return p[0] * pow_(u1 / (1.0 - u1), 1.0 / p[1]);  // loglogistic.py:107-109
+  if constexpr (D == M355_LOGLOGISTIC) return p[0] * exp_(flog_tab(u1 / (1.0 - u1)) / p[1]);  // loglogistic.py:107-109
   return kNaN;
 }
 
@@ -666,7 +666,7 @@ template <int D> constexpr bool one_normal() {
 template <int D> M355_DEV double from_normal(double z, const double* p) {
   if constexpr (D == M355_LOGNORMAL) return exp_(p[0] + p[1] * z);       // lognormal.py:68-69
   if constexpr (D == M355_HALFNORMAL) return __builtin_fabs(p[0] * z);   // halfnormal.py:62-63
-  if constexpr (D == M355_MOYAL) return p[0] - p[1] * flog(z * z);       // moyal.py:66-68: ppf(U) = mu - sigma log Z^2
+  if constexpr (D == M355_MOYAL) return p[0] - p[1] * flog_tab(z * z);  // moyal.py:66-68: ppf(U) = mu - sigma log Z^2
   if constexpr (D == M355_LOGITNORMAL) return sigmoid_(p[0] + p[1] * z);  // logitnormal.py:191-192
   return kNaN;
 }
