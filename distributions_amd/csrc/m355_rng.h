@@ -807,18 +807,22 @@ template <int D> M355_DEV double sample_one(unsigned long long idx, unsigned lon
     double w = 1.0;
     for (int it = 0; it < kMaxAttempts; ++it) {
       next_pair(st, u1, u2);
-      const double z = ::cos(kPi * u1);
+      double sn, z;
+      sincos_2pi(0.5 * u1, sn, z);  // z = cos(pi u1) (the device libm's cos, with its general reduction, cost 2.5 times that)
       w = (1.0 + s * z) / (s + z);
       const double y = kappa * (s - w);
-      if ((y * (2.0 - y) - u2 >= 0.0) || (flog(y / u2) + 1.0 - y >= 0.0)) break;
+      if ((y * (2.0 - y) - u2 >= 0.0) || (flog_tab(y / u2) + 1.0 - y >= 0.0)) break;
     }
     next_pair(st, u1, u2);
     double res = ::acos(w);
     if (u1 < 0.5) res = -res;
     res += mu;
     const bool neg = res < 0.0;
-    double m = __builtin_fabs(res);
-    m = ::fmod(m + kPi, 2.0 * kPi) - kPi;
+    double m = __builtin_fabs(res) + kPi;
+    // fmod(m, 2 pi): below 4 pi it is m or m - 2 pi, and that subtraction is exact -- the same value without fmod's loop
+    if (m >= 4.0 * kPi) m = ::fmod(m, 2.0 * kPi);
+    else if (m >= 2.0 * kPi) m -= 2.0 * kPi;
+    m -= kPi;
     return neg ? -m : m;
   } else if constexpr (D == M355_INVERSEGAMMA) {  // inversegamma.py:69-70: 1 / Gamma(alpha, rate beta)
     return p[1] / sample_std_gamma(st, p[0]);
