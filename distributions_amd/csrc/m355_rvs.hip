@@ -36,20 +36,29 @@ __global__ __launch_bounds__(kBlock) void k_rvs(GenericOps ops, void* __restrict
 
 // Families drawn from ONE uniform or ONE normal per element (m355_rng.h one_uniform / one_normal), any parameter layout:
 // a thread turns the Philox block of elements 2k, 2k + 1 into both draws and stores 16 bytes.  Same draws as k_rvs.
-template <int D>
+// SCALARS: every parameter is a scalar -- they are read once in front of the loop, so whatever a family derives from its
+// parameters alone (truncatednormal's cdf at the bounds, geometric's log1p(-p), ...) is loop-invariant and the compiler
+// hoists it; the arithmetic per draw is unchanged (same draws as the general variant).
+template <int D, bool SCALARS = false>
 __global__ __launch_bounds__(kBlock) void k_rvs_pairs(GenericOps ops, void* __restrict__ out, int odt, long long npairs,
                                                       unsigned long long seed, unsigned stream, unsigned long long pair_offset) {
   log_table_init();
   const bool small = 2 * npairs <= 0xffffffffll;
   const unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
+  double pa[kMaxParams] = {0.0, 0.0, 0.0, 0.0}, pb[kMaxParams] = {0.0, 0.0, 0.0, 0.0};
+  if constexpr (SCALARS) {
+#pragma unroll
+    for (int q = 0; q < Dist<D>::NP; ++q) pa[q] = pb[q] = ops.p[q].scalar;
+  }
   for (long long k = (long long)blockIdx.x * kBlock + threadIdx.x; k < npairs; k += (long long)gridDim.x * kBlock) {
     const unsigned long long c = pair_offset + (unsigned long long)k;
     const Philox b = philox4x32_10((unsigned)c, (unsigned)(c >> 32), 0u, stream, k0, k1);
-    double pa[kMaxParams] = {0.0, 0.0, 0.0, 0.0}, pb[kMaxParams] = {0.0, 0.0, 0.0, 0.0};
+    if constexpr (!SCALARS) {
 #pragma unroll
-    for (int q = 0; q < Dist<D>::NP; ++q) {
-      pa[q] = fetch_operand(ops.p[q], 2ull * (unsigned long long)k, small);
-      pb[q] = fetch_operand(ops.p[q], 2ull * (unsigned long long)k + 1ull, small);
+      for (int q = 0; q < Dist<D>::NP; ++q) {
+        pa[q] = fetch_operand(ops.p[q], 2ull * (unsigned long long)k, small);
+        pb[q] = fetch_operand(ops.p[q], 2ull * (unsigned long long)k + 1ull, small);
+      }
     }
     double v0, v1;
     if constexpr (one_uniform<D>()) {
@@ -962,7 +971,12 @@ template <int D> int launch_rvs_any(const GenericOps& ops, void* out, int odt, l
       const long long npairs = n / 2;
       const long long want = (npairs + kBlock - 1) / kBlock;
       const int blocks = (int)(want > kMaxBlocks ? kMaxBlocks : want);
-      hipLaunchKernelGGL((k_rvs_pairs<D>), dim3(blocks), dim3(kBlock), 0, s, ops, out, odt, npairs, seed, stream, offset >> 1);
+      bool scalars = true;
+      for (int q = 0; q < Dist<D>::NP; ++q) scalars &= ops.p[q].ptr == nullptr;
+      if (scalars)
+        hipLaunchKernelGGL((k_rvs_pairs<D, true>), dim3(blocks), dim3(kBlock), 0, s, ops, out, odt, npairs, seed, stream, offset >> 1);
+      else
+        hipLaunchKernelGGL((k_rvs_pairs<D>), dim3(blocks), dim3(kBlock), 0, s, ops, out, odt, npairs, seed, stream, offset >> 1);
       const int rc = (int)hipGetLastError();
       if (rc != 0 || (n & 1) == 0) return rc;
       return launch_rvs<D>(ops, static_cast<char*>(out) + 8 * (n - 1), odt, 1, seed, stream, offset + (unsigned long long)(n - 1), s,
