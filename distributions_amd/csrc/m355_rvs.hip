@@ -20,16 +20,24 @@ M355_DEV void store_draw(void* out, int odt, long long i, double v) {
 // stream: 8 B per draw, coalesced 512 B per wavefront store.
 // first: the call's element that out[0] holds (a pair kernel leaves an odd last element to this one: its parameters are
 // those of element `first`, not of element 0)
-template <int D>
+// SCALARS: every parameter is a scalar, read once in front of the loop -- a sampler's parameter-only set-up (von Mises' s,
+// the Marsaglia-Tsang constants, ...) is then loop-invariant and hoisted; the arithmetic of a draw is unchanged.
+template <int D, bool SCALARS = false>
 __global__ __launch_bounds__(kBlock) void k_rvs(GenericOps ops, void* __restrict__ out, int odt, long long n,
                                                 unsigned long long seed, unsigned stream,
                                                 unsigned long long offset, long long first) {
   log_table_init();  // the samplers use flog_tab
   const bool small = first + n <= 0xffffffffll;
-  for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < n; i += (long long)gridDim.x * kBlock) {
-    double pp[kMaxParams] = {0.0, 0.0, 0.0, 0.0};
+  double pp[kMaxParams] = {0.0, 0.0, 0.0, 0.0};
+  if constexpr (SCALARS) {
 #pragma unroll
-    for (int q = 0; q < Dist<D>::NP; ++q) pp[q] = fetch_operand(ops.p[q], (unsigned long long)(first + i), small);
+    for (int q = 0; q < Dist<D>::NP; ++q) pp[q] = ops.p[q].scalar;
+  }
+  for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < n; i += (long long)gridDim.x * kBlock) {
+    if constexpr (!SCALARS) {
+#pragma unroll
+      for (int q = 0; q < Dist<D>::NP; ++q) pp[q] = fetch_operand(ops.p[q], (unsigned long long)(first + i), small);
+    }
     store_draw(out, odt, i, sample_one<D>(offset + (unsigned long long)i, seed, stream, pp));
   }
 }
@@ -958,7 +966,12 @@ template <int D> int launch_rvs(const GenericOps& ops, void* out, int odt, long 
                                 unsigned stream, unsigned long long offset, hipStream_t s, long long first = 0) {
   const long long want = (n + kBlock - 1) / kBlock;
   const int blocks = (int)(want < 1 ? 1 : (want > kMaxBlocks ? kMaxBlocks : want));
-  hipLaunchKernelGGL((k_rvs<D>), dim3(blocks), dim3(kBlock), 0, s, ops, out, odt, n, seed, stream, offset, first);
+  bool scalars = n >= 4096;  // (a short call gains nothing from the second instantiation)
+  for (int q = 0; q < Dist<D>::NP; ++q) scalars &= ops.p[q].ptr == nullptr;
+  if (scalars)
+    hipLaunchKernelGGL((k_rvs<D, true>), dim3(blocks), dim3(kBlock), 0, s, ops, out, odt, n, seed, stream, offset, first);
+  else
+    hipLaunchKernelGGL((k_rvs<D>), dim3(blocks), dim3(kBlock), 0, s, ops, out, odt, n, seed, stream, offset, first);
   return (int)hipGetLastError();
 }
 

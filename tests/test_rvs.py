@@ -597,6 +597,27 @@ def test_gpu_array_parameter_count_compaction(gpu, hostlib, name):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("name, params", [("skewnormal", (0.5, 1.5, 2.0)), ("exgaussian", (0.0, 1.0, 2.0)), ("wald", (1.0, 2.0)),
+                                          ("vonmises", (0.5, 2.0)), ("rice", (1.0, 2.0)), ("halfstudentt", (5.0, 2.0)),
+                                          ("halfstudentt", (0.6, 1.0)), ("polyagamma", (1.0, 0.5)), ("truncatednormal", (0.0, 1.0, -1.0, 2.0)),
+                                          ("skew_studentt", (0.0, 1.0, 3.0, 4.0)), ("geometric", (0.2,)), ("kumaraswamy", (2.0, 3.0))])
+def test_gpu_scalar_parameter_variants_equal_general_kernels(gpu, name, params):
+    """k_rvs<D, SCALARS> / k_rvs_pairs<D, SCALARS> (all parameters scalar, read once in front of the loop; n >= 4096 for
+    k_rvs) give the draws of the general kernels: the same call with one parameter passed as a constant array, and calls
+    below 4096 elements at the matching offsets."""
+    import importlib
+
+    m = importlib.import_module(f"distributions_amd.{name}")
+    n = 30_001
+    a = m.rvs(*params, size=n, random_state=41)
+    b = m.rvs(np.full(n, params[0]), *params[1:], size=n, random_state=41)
+    assert np.array_equal(a, b, equal_nan=True)
+    for off in (0, 4000, 27_502):
+        cnt = min(2499, n - off)
+        assert np.array_equal(a[off:off + cnt], m.rvs(*params, size=cnt, random_state=(41, off)), equal_nan=True)
+
+
+@pytest.mark.gpu
 def test_gpu_array_parameter_kernels_dtypes_and_lengths(gpu):
     """The array-parameter compaction kernels through the C-ABI: float32 / int64 outputs, a misaligned `out`, lengths on both sides of the 4096-element switch from the per-lane loop -- the draws of element i do
     not depend on any of it, and nothing is written outside [0, n)."""
