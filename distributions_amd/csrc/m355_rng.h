@@ -678,6 +678,35 @@ template <int D> M355_DEV double from_normal(double z, const double* p) {
   return kNaN;
 }
 
+// von Mises by Best & Fisher's wrapped-Cauchy rejection (numpy's random_vonmises), kappa >= 1e-8: the kappa-only constant,
+// one attempt from a uniform pair, and the last step (sign from another uniform, shift by mu, wrap into [-pi, pi]).  Shared
+// by the per-lane loop (sample_one) and the compacting kernel (k_rvs_vm).
+M355_DEV double vm_setup(double kappa) {
+  if (kappa < 1e-5) return 1.0 / kappa + kappa;
+  const double r = 1.0 + fsqrt(1.0 + 4.0 * kappa * kappa);
+  const double rho = (r - fsqrt(2.0 * r)) / (2.0 * kappa);
+  return (1.0 + rho * rho) / (2.0 * rho);
+}
+M355_DEV bool vm_attempt(double s, double kappa, double u1, double u2, double& w) {
+  double sn, z;
+  sincos_2pi(0.5 * u1, sn, z);  // z = cos(pi u1) (the device libm's cos, with its general reduction, cost 2.5 times that)
+  w = (1.0 + s * z) / (s + z);
+  const double y = kappa * (s - w);
+  return (y * (2.0 - y) - u2 >= 0.0) || (flog_tab(y / u2) + 1.0 - y >= 0.0);
+}
+M355_DEV double vm_finish(double w, double u1, double mu) {
+  double res = ::acos(w);
+  if (u1 < 0.5) res = -res;
+  res += mu;
+  const bool neg = res < 0.0;
+  double m = __builtin_fabs(res) + kPi;
+  // fmod(m, 2 pi): below 4 pi it is m or m - 2 pi, and that subtraction is exact -- the same value without fmod's loop
+  if (m >= 4.0 * kPi) m = ::fmod(m, 2.0 * kPi);
+  else if (m >= 2.0 * kPi) m -= 2.0 * kPi;
+  m -= kPi;
+  return neg ? -m : m;
+}
+
 // One draw of distribution D for global element index `idx` (parameters already fetched).
 template <int D> M355_DEV double sample_one(unsigned long long idx, unsigned long long seed, unsigned stream,
                                            const double* p) {
@@ -796,34 +825,14 @@ template <int D> M355_DEV double sample_one(unsigned long long idx, unsigned lon
       next_pair(st, u1, u2);
       return kPi * (2.0 * u1 - 1.0);
     }
-    double s;
-    if (kappa < 1e-5) {
-      s = 1.0 / kappa + kappa;
-    } else {
-      const double r = 1.0 + fsqrt(1.0 + 4.0 * kappa * kappa);
-      const double rho = (r - fsqrt(2.0 * r)) / (2.0 * kappa);
-      s = (1.0 + rho * rho) / (2.0 * rho);
-    }
+    const double s = vm_setup(kappa);
     double w = 1.0;
     for (int it = 0; it < kMaxAttempts; ++it) {
       next_pair(st, u1, u2);
-      double sn, z;
-      sincos_2pi(0.5 * u1, sn, z);  // z = cos(pi u1) (the device libm's cos, with its general reduction, cost 2.5 times that)
-      w = (1.0 + s * z) / (s + z);
-      const double y = kappa * (s - w);
-      if ((y * (2.0 - y) - u2 >= 0.0) || (flog_tab(y / u2) + 1.0 - y >= 0.0)) break;
+      if (vm_attempt(s, kappa, u1, u2, w)) break;
     }
     next_pair(st, u1, u2);
-    double res = ::acos(w);
-    if (u1 < 0.5) res = -res;
-    res += mu;
-    const bool neg = res < 0.0;
-    double m = __builtin_fabs(res) + kPi;
-    // fmod(m, 2 pi): below 4 pi it is m or m - 2 pi, and that subtraction is exact -- the same value without fmod's loop
-    if (m >= 4.0 * kPi) m = ::fmod(m, 2.0 * kPi);
-    else if (m >= 2.0 * kPi) m -= 2.0 * kPi;
-    m -= kPi;
-    return neg ? -m : m;
+    return vm_finish(w, u1, mu);
   } else if constexpr (D == M355_INVERSEGAMMA) {  // inversegamma.py:69-70: 1 / Gamma(alpha, rate beta)
     return p[1] / sample_std_gamma(st, p[0]);
   } else if constexpr (D == M355_CHISQUARED) {  // chisquared.py:59-60

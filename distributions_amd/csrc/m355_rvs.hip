@@ -801,6 +801,61 @@ template <int D> bool try_rvs_bb(const GenericOps& ops, void* out, int odt, long
   return true;
 }
 
+// von Mises with scalar parameters (kappa >= 1e-8): Best & Fisher's attempts (m355_rng.h) with the lane refill -- the
+// acceptance rate falls to 66 % as kappa grows, and the per-lane loop had a wavefront wait for its slowest lane.  The
+// sign uniform is the block after the accepted attempt, as in sample_one: same draws as k_rvs.
+__global__ __launch_bounds__(kBlock) void k_rvs_vm(void* __restrict__ out, int odt, long long n, double mu, double kappa,
+                                                   unsigned long long seed, unsigned stream, unsigned long long offset) {
+  log_table_init();
+  const long long wave = (long long)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  const long long nwaves = (long long)gridDim.x * (kBlock / 64);
+  const long long chunk = ((n + nwaves - 1) / nwaves + 63) & ~63ll;
+  const long long w1 = (wave + 1) * chunk < n ? (wave + 1) * chunk : n;
+  long long next = wave * chunk;  // wave-uniform: first unassigned element
+  if (next >= w1) return;
+  const double s = vm_setup(kappa);
+  long long idx = -1;  // element held by this lane (-1: none)
+  unsigned attempt = 0;
+  for (;;) {
+    const bool freed = idx < 0;
+    const unsigned long long fm = __ballot(freed);
+    const unsigned below = __builtin_amdgcn_mbcnt_hi((unsigned)(fm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)fm, 0u));
+    if (freed) {
+      const long long cand = next + below;
+      if (cand < w1) {
+        idx = cand;
+        attempt = 0;
+      }
+    }
+    next += __popcll(fm);
+    if (next > w1) next = w1;
+    const bool active = idx >= 0;
+    if (__ballot(active) == 0ull) break;  // chunk exhausted and every lane has stored its draw
+    if (active) {
+      const unsigned long long c = offset + (unsigned long long)idx;
+      const Philox ph = philox4x32_10((unsigned)c, (unsigned)(c >> 32), attempt, stream, (unsigned)seed, (unsigned)(seed >> 32));
+      attempt += 1;
+      double w;
+      if (vm_attempt(s, kappa, u53(ph.c[0], ph.c[1]), u53(ph.c[2], ph.c[3]), w) || attempt >= (unsigned)kMaxAttempts) {
+        const Philox pf = philox4x32_10((unsigned)c, (unsigned)(c >> 32), attempt, stream, (unsigned)seed, (unsigned)(seed >> 32));
+        store_draw(out, odt, idx, vm_finish(w, u53(pf.c[0], pf.c[1]), mu));
+        idx = -1;
+      }
+    }
+  }
+}
+inline bool try_rvs_vm(const GenericOps& ops, void* out, int odt, long long n, unsigned long long seed, unsigned stream,
+                       unsigned long long offset, hipStream_t s, int* rc) {
+  if (n < 4096 || ops.p[0].ptr != nullptr || ops.p[1].ptr != nullptr) return false;
+  const double kappa = ops.p[1].scalar;
+  if (!(kappa >= 1e-8) || !(kappa < kInf)) return false;  // (uniform limit, invalid or infinite kappa: sample_one's branches)
+  const long long want = (n + 4 * kBlock - 1) / (4 * kBlock);  // >= 256 elements per wavefront
+  const int blocks = (int)(want > 8192 ? 8192 : want);
+  hipLaunchKernelGGL(k_rvs_vm, dim3(blocks), dim3(kBlock), 0, s, out, odt, n, ops.p[0].scalar, kappa, seed, stream, offset);
+  *rc = (int)hipGetLastError();
+  return true;
+}
+
 // beta / betascaled with parameters given as ARRAYS: the BB constants are set up when a lane takes its element; an
 // element with a shape at or below 1 (or a degenerate one) is drawn on the spot by sample_one's gamma-ratio branch.
 // Bit-identical to the per-lane loop of k_rvs.
@@ -1085,6 +1140,7 @@ extern "C" int m355_rvs_impl(int dist, int out_dtype, long long n, const m355::G
                try_rvs_mt<M355_BETASCALED>(*ops, out, out_dtype, n, seed, stream_id, offset, s, &rc) ||
                try_rvs_bb_arr<M355_BETASCALED>(*ops, out, out_dtype, n, seed, stream_id, offset, s, &rc);
         break;
+      case M355_VONMISES: done = try_rvs_vm(*ops, out, out_dtype, n, seed, stream_id, offset, s, &rc); break;
       case M355_ZI_POISSON: done = try_rvs_zi_arr<M355_ZI_POISSON>(*ops, out, out_dtype, n, seed, stream_id, offset, s, &rc); break;
       case M355_ZI_BINOMIAL: done = try_rvs_zi_arr<M355_ZI_BINOMIAL>(*ops, out, out_dtype, n, seed, stream_id, offset, s, &rc); break;
       default: break;

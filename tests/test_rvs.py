@@ -598,12 +598,13 @@ def test_gpu_array_parameter_count_compaction(gpu, hostlib, name):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("name, params", [("skewnormal", (0.5, 1.5, 2.0)), ("exgaussian", (0.0, 1.0, 2.0)), ("wald", (1.0, 2.0)),
-                                          ("vonmises", (0.5, 2.0)), ("rice", (1.0, 2.0)), ("halfstudentt", (5.0, 2.0)),
+                                          ("vonmises", (0.5, 2.0)), ("vonmises", (-2.0, 50.0)), ("vonmises", (0.5, 1e-6)),
+                                          ("vonmises", (0.0, 1e-9)), ("rice", (1.0, 2.0)), ("halfstudentt", (5.0, 2.0)),
                                           ("halfstudentt", (0.6, 1.0)), ("polyagamma", (1.0, 0.5)), ("truncatednormal", (0.0, 1.0, -1.0, 2.0)),
                                           ("skew_studentt", (0.0, 1.0, 3.0, 4.0)), ("geometric", (0.2,)), ("kumaraswamy", (2.0, 3.0))])
 def test_gpu_scalar_parameter_variants_equal_general_kernels(gpu, name, params):
     """k_rvs<D, SCALARS> / k_rvs_pairs<D, SCALARS> (all parameters scalar, read once in front of the loop; n >= 4096 for
-    k_rvs) give the draws of the general kernels: the same call with one parameter passed as a constant array, and calls
+    k_rvs) and k_rvs_vm (von Mises with the lane refill, kappa >= 1e-8) give the draws of the general kernels: the same call with one parameter passed as a constant array, and calls
     below 4096 elements at the matching offsets."""
     import importlib
 
