@@ -844,15 +844,14 @@ template <int D> M355_DEV double sample_one(unsigned long long idx, unsigned lon
     const double ga = sample_std_gamma(st, p[0]);
     const double gb = sample_std_gamma(st, p[1]);
     return ga / (ga + gb) * (p[3] - p[2]) + p[2];
+  } else if constexpr (D == M355_HALFSTUDENTT) {  // halfstudentt.py:117-119: |sigma * z / sqrt(chi2_nu / nu)|
+    // as studentt: the normal is the second Box-Muller output of the accepted gamma attempt's block
+    const double a = 0.5 * p[0];
+    double z0 = 0.0;
+    if (!(a > 0.0) || a == kInf) z0 = normal_single(philox4x32_10(st.idx_lo, st.idx_hi, 0x7fffffffu, st.stream, st.k0, st.k1));
+    const double g = sample_std_gamma<true>(st, a, &z0);
+    return __builtin_fabs(z0 * fsqrt(a / g) * p[1]);
   } else {
-    // samplers driven by one normal pair and / or one uniform pair
-    double u1, u2, z0, z1;
-    next_pair(st, u1, u2);
-    if constexpr (D == M355_HALFSTUDENTT) {                                               // halfstudentt.py:117-119
-      normal_pair(u1, u2, z0, z1);
-      const double g = sample_std_gamma(st, 0.5 * p[0]);
-      return __builtin_fabs(z0 * fsqrt(0.5 * p[0] / g) * p[1]);
-    }
     return kNaN;
   }
 }

@@ -591,6 +591,12 @@ template <> struct MtPlan<M355_STUDENTT> {
   static M355_HD double shape(const double* p, int) { return 0.5 * p[0]; }
   static M355_DEV double finish(const double* p, double z0, double g) { return p[1] + p[2] * z0 * fsqrt(0.5 * p[0] / g); }
 };
+template <> struct MtPlan<M355_HALFSTUDENTT> {
+  static constexpr int kStages = 1;  // (the same construction, folded)
+  static M355_HD double shape(const double* p, int) { return 0.5 * p[0]; }
+  static M355_DEV double finish(const double* p, double z0, double g) { return __builtin_fabs(z0 * fsqrt(0.5 * p[0] / g) * p[1]); }
+};
+template <int D> constexpr bool mt_wants_z() { return D == M355_STUDENTT || D == M355_HALFSTUDENTT; }
 
 struct MtParams {
   double p[kMaxParams];
@@ -640,7 +646,7 @@ __global__ __launch_bounds__(kBlock) void k_rvs_mt(void* __restrict__ out, int o
       kk.c = stage == 0 ? k0.c : k1.c;
       double g, x;
       bool ok;
-      if constexpr (D == M355_STUDENTT) ok = mt_attempt<true>(kk, ph, g, x, &hold);
+      if constexpr (mt_wants_z<D>()) ok = mt_attempt<true>(kk, ph, g, x, &hold);
       else ok = mt_attempt(kk, ph, g, x);
       if (ok || attempt >= (unsigned)kMaxAttempts) {
         const double as = stage == 0 ? a0 : a1;
@@ -716,7 +722,7 @@ __global__ __launch_bounds__(kBlock) void k_rvs_mt_arr(GenericOps ops, void* __r
       attempt += 1;
       double g, x;
       bool ok;
-      if constexpr (D == M355_STUDENTT) ok = mt_attempt<true>(kk, ph, g, x, &hold);
+      if constexpr (mt_wants_z<D>()) ok = mt_attempt<true>(kk, ph, g, x, &hold);
       else ok = mt_attempt(kk, ph, g, x);
       if (ok || attempt >= (unsigned)kMaxAttempts) {
         if (shape < 1.0) {
@@ -1129,6 +1135,7 @@ extern "C" int m355_rvs_impl(int dist, int out_dtype, long long n, const m355::G
       M355_MT1_CASE(M355_CHISQUARED)
       M355_MT1_CASE(M355_SCALEDINVERSECHISQUARED)
       M355_MT1_CASE(M355_STUDENTT)
+      M355_MT1_CASE(M355_HALFSTUDENTT)
 #undef M355_MT1_CASE
       case M355_BETA:
         done = try_rvs_bb<M355_BETA>(*ops, out, out_dtype, n, seed, stream_id, offset, s, &rc) ||

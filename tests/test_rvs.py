@@ -17,6 +17,17 @@ _dp = ctypes.POINTER(ctypes.c_double)
 _u32p = ctypes.POINTER(ctypes.c_uint32)
 from distributions_amd._lib import DIST  # ids of include/m355_dist.h (pure Python, no library load)
 
+class _folded:
+    """|X| for a scipy distribution symmetric about 0 (the cdf the KS tests read)."""
+
+    def __init__(self, d):
+        self.d = d
+
+    def cdf(self, x):
+        x = np.asarray(x, dtype=float)
+        return np.where(x < 0, 0.0, 2.0 * self.d.cdf(x) - 1.0)
+
+
 CONT = [
     ("normal", (0.3, 1.7), stats.norm(0.3, 1.7)),
     ("gamma", (2.5, 1.3), stats.gamma(2.5, scale=1 / 1.3)),   # Marsaglia-Tsang
@@ -513,7 +524,7 @@ def test_gpu_array_parameter_compaction(gpu, hostlib, name):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["gamma", "inversegamma", "chisquared", "scaledinversechisquared", "studentt"])
+@pytest.mark.parametrize("name", ["gamma", "inversegamma", "chisquared", "scaledinversechisquared", "studentt", "halfstudentt"])
 def test_gpu_array_parameter_mt_compaction(gpu, hostlib, name):
     """k_rvs_mt_arr (one Marsaglia-Tsang stage, one parameter set per element, n >= 4096) gives the draws of the per-lane
     loop of k_rvs (calls below 4096 elements): shapes from 0.05 to 1e4 (boost below 1), a few degenerate ones."""
@@ -527,7 +538,8 @@ def test_gpu_array_parameter_mt_compaction(gpu, hostlib, name):
     shape[1::101] = np.inf
     scale = np.exp(rng.uniform(-2.0, 2.0, n))
     params = {"gamma": (shape, scale), "inversegamma": (shape, scale), "chisquared": (2.0 * shape,),
-              "scaledinversechisquared": (2.0 * shape, scale), "studentt": (2.0 * shape, rng.normal(size=n), scale)}[name]
+              "scaledinversechisquared": (2.0 * shape, scale), "studentt": (2.0 * shape, rng.normal(size=n), scale),
+              "halfstudentt": (2.0 * shape, scale)}[name]
     with np.errstate(all="ignore"):
         a = m.rvs(*params, size=n, random_state=23)
         for off in (0, 3000, 77_777, n - 2500):
@@ -538,7 +550,7 @@ def test_gpu_array_parameter_mt_compaction(gpu, hostlib, name):
     assert np.isfinite(a[ok]).all()
     # the law at fixed parameters passed as arrays, against the scalar-parameter kernel's sample
     fixed = {"gamma": (2.5, 1.3), "inversegamma": (3.0, 2.0), "chisquared": (7.0,), "scaledinversechisquared": (4.0, 1.5),
-             "studentt": (5.0, 0.0, 2.0)}[name]
+             "studentt": (5.0, 0.0, 2.0), "halfstudentt": (5.0, 2.0)}[name]
     x = m.rvs(*[np.full(400_000, v) for v in fixed], size=400_000, random_state=24)
     y = m.rvs(*fixed, size=400_000, random_state=25)
     assert stats.ks_2samp(x, y).pvalue > 1e-3
@@ -748,6 +760,7 @@ FAMILY_RVS = [
     ("chisquared", (5.0,), lambda: stats.chi2(df=5.0)),
     ("scaledinversechisquared", (10.0, 2.0), lambda: stats.invgamma(a=5.0, scale=10.0)),
     ("halfstudentt", (1.0, 3.5), lambda: stats.halfcauchy(scale=3.5)),
+    ("halfstudentt", (5.0, 2.0), lambda: _folded(stats.t(df=5.0, scale=2.0))),
     ("betascaled", (2.0, 5.0, -1.0, 3.0), lambda: stats.beta(a=2.0, b=5.0, loc=-1.0, scale=4.0)),
     ("wald", (2.0, 10.0), lambda: stats.invgauss(mu=0.2, scale=10.0)),
     ("exgaussian", (1.0, 3.0, 3.0), lambda: stats.exponnorm(K=1.0, loc=1.0, scale=3.0)),
