@@ -254,6 +254,9 @@ int m355_logpdf_grad(int dist, int out_dtype, int64_t n, const m355_operand* x, 
  * hypergeometric, zi_*) are sampled by inversion on a tabulated cdf when EVERY parameter is a scalar operand, and by the
  * per-lane rejection / mixture samplers when a parameter is an array: the two forms give different (equally distributed)
  * streams for the same parameter values; within one form the split-invariance above holds.
+ * The map (seed, stream, element) -> draw belongs to a build of the library, not to the interface: samplers have been
+ * replaced between releases (ziggurat normal, Cheng's beta, the half Student t), so stored draws are reproducible only
+ * with the build that made them.
  */
 int m355_rvs(int dist, int out_dtype, int64_t n, int nparams, const m355_operand* params, uint64_t seed,
              uint32_t stream_id, uint64_t counter_offset, void* out, void* stream);
